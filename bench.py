@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the distance + top-k hot path (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch: the brute-force k-NN search of M
+queries against the N-row fp32 base (config C2: N=1M, d=128, M=10k, k=10, L2), inputs
+resident in HBM.  With --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) the
+base is sharded by contiguous row ranges (strong scaling: total N fixed), every rank scans
+its shard for all queries, the per-shard top-k are all-gathered over RCCL and merged.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel, timed with HIP events on its stream inside the library) and `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--m", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="l2")
+    ap.add_argument("--query-tile", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="rough budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(base_host, queries_host, k, budget_s):
+    """Time the CPU oracle (kind 'port': oracle/expann_oracle.c, a restatement of
+    src/brute_force_engine.h:28-46 + src/distance.h:136-147) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_ctypes as oc
+    lib = None
+    try:  # a -march=native build for the host we are on; fall back to the shipped x86-64-v3 one
+        out_dir = os.path.join(ROOT, "gpurun_out", "oracle_native")
+        lib = oc.lib(oc.build(arch_flags=["-march=native"], out_dir=out_dir))
+        flags = "-O3 -march=native"
+    except Exception:
+        lib = oc.lib()
+        flags = "-O3 -march=x86-64-v3 (prebuilt)"
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # 1 thread: the reference's execution model (src/basic_bench.h:83-84)
+    t0 = time.perf_counter()
+    oc.brute_force(base_host, queries_host[:2], k, oc.METRIC_L2_F32, 1, _lib_override=lib)
+    t1 = (time.perf_counter() - t0) / 2
+    n1 = max(2, min(32, int(budget_s * 0.35 / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    oc.brute_force(base_host, queries_host[:n1], k, oc.METRIC_L2_F32, 1, _lib_override=lib)
+    qps1 = n1 / (time.perf_counter() - t0)
+    # all cores, queries partitioned over threads (extension)
+    nall = max(cores, min(len(queries_host), int(budget_s * 0.65 * qps1 * cores * 0.5)))
+    nall = (nall // cores) * cores or cores
+    t0 = time.perf_counter()
+    oc.brute_force(base_host, queries_host[:nall], k, oc.METRIC_L2_F32, cores, _lib_override=lib)
+    qps_all = nall / (time.perf_counter() - t0)
+    return {"value": round(qps_all, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{nall} of the step's queries x all {base_host.shape[0]} rows on {cores} "
+                      f"threads ({flags}); 1 thread: {qps1:.2f} queries/s over {n1} queries",
+            "single_thread_value": round(qps1, 2)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    G = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from expann_amd import GpuBruteForceEngine, merge_topk_device
+
+    # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
+    lo = rank * a.n // G
+    hi = (rank + 1) * a.n // G
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
+    g.manual_seed(4321)
+    queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
+
+    eng = GpuBruteForceEngine(a.d, a.metric, device=local_rank)
+    eng.set_base_device(base.data_ptr(), hi - lo, lo)
+    if a.query_tile:
+        eng.set_option("query_tile", a.query_tile)
+    ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
+    dists = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
+    if G > 1:
+        all_ids = torch.empty(G, a.m, a.k, dtype=torch.int64, device=dev)
+        all_d = torch.empty(G, a.m, a.k, dtype=torch.float32, device=dev)
+        out_ids = torch.empty_like(ids)
+        out_d = torch.empty_like(dists)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.search_device(queries.data_ptr(), a.m, a.k, ids.data_ptr(), dists.data_ptr(), stream)
+        if G > 1:
+            dist.all_gather_into_tensor(all_ids, ids)
+            dist.all_gather_into_tensor(all_d, dists)
+            merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), G, a.m, a.k,
+                              out_ids.data_ptr(), out_d.data_ptr(), stream)
+
+    for _ in range(a.warmup):
+        step()
+    eng.set_profiling(True)
+    if G > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if G > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if G > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / a.steps
+        qps = a.m * a.steps / elapsed
+        launches = max(1, prof["scan_launches"])
+        scan_ms = prof["scan_ms"] / launches
+        n_local = hi - lo
+        passes = prof["scan_query_tiles"] / launches
+        alg_bytes = passes * n_local * a.d * 4          # one pass of a query tile = N*d*4 B
+        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": prof["scan_kernel"], "kernel_ms": round(scan_ms, 4),
+                    "launches": int(launches), "query_tile": int(prof["query_tile"]),
+                    "passes_per_launch": passes,
+                    "single_pass_equiv_GBps": round(n_local * a.d * 4 / (scan_ms * 1e-3) / 1e9, 2)
+                    if scan_ms > 0 else 0.0,
+                    "flops_direct_TFLOPs": round(3.0 * n_local * a.d * a.m / (scan_ms * 1e-3) / 1e12, 2)
+                    if scan_ms > 0 else 0.0,
+                    "candidates_per_query": round(prof["candidates"] / a.m, 1)}
+        out = {"metric": "queries/sec at recall@10=1.0 (exact brute force), 1Mxd128 fp32, k=10",
+               "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"brute_force_engine L2 N={a.n} d={a.d} fp32, "
+                                      f"{a.m} batched queries, k={a.k} (BASELINE configs[1])",
+                          "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
+                          "sharding": f"rows/{G}" if G > 1 else "none"},
+               "roofline": roofline}
+        if G == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(base.cpu().numpy(), queries.cpu().numpy(), a.k,
+                                                   a.cpu_seconds)
+            except Exception as e:  # the baseline is a reported extra, never the product
+                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
+                                       "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if G > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

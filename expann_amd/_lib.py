@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI in include/expann_hip.h (libexpann_hip.so, built in-tree by
+__graft_entry__.build()).  There is no fallback: if the shared library is missing the import
+of any compute entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexpann_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_BUILT, ERR_UNSUPPORTED, ERR_OVERFLOW = 1, 2, 3, 4, 5, 6
+DTYPE_F32, DTYPE_U8, DTYPE_I8 = 0, 1, 2
+METRIC_L2, METRIC_IP, METRIC_L2_I8_REFCOMPAT = 0, 1, 2
+
+# every symbol include/expann_hip.h declares
+ABI_SYMBOLS = [
+    "expann_abi_version", "expann_device_count", "expann_create", "expann_destroy",
+    "expann_last_error", "expann_add", "expann_build", "expann_set_base_device", "expann_size",
+    "expann_search", "expann_search_device", "expann_merge_topk_device", "expann_score_ids",
+    "expann_set_profiling", "expann_get_profile", "expann_set_option",
+]
+
+
+class Profile(C.Structure):
+    _fields_ = [("scan_launches", C.c_uint64), ("scan_ms", C.c_double), ("scan_rows", C.c_uint64),
+                ("scan_query_tiles", C.c_uint64), ("query_tile", C.c_uint32),
+                ("levels", C.c_uint32), ("candidates", C.c_uint64), ("retries", C.c_uint64),
+                ("scan_kernel", C.c_char * 64)]
+
+
+class ExpannError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"expann_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libexpann_hip.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    L.expann_abi_version.restype = C.c_int
+    L.expann_device_count.restype = C.c_int
+    L.expann_create.restype = C.c_int
+    L.expann_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.expann_destroy.restype = None
+    L.expann_destroy.argtypes = [vp]
+    L.expann_last_error.restype = C.c_char_p
+    L.expann_last_error.argtypes = [vp]
+    L.expann_add.restype = C.c_int
+    L.expann_add.argtypes = [vp, vp, sz]
+    L.expann_build.restype = C.c_int
+    L.expann_build.argtypes = [vp]
+    L.expann_set_base_device.restype = C.c_int
+    L.expann_set_base_device.argtypes = [vp, vp, sz, u64]
+    L.expann_size.restype = sz
+    L.expann_size.argtypes = [vp]
+    L.expann_search.restype = C.c_int
+    L.expann_search.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.expann_search_device.restype = C.c_int
+    L.expann_search_device.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.expann_merge_topk_device.restype = C.c_int
+    L.expann_merge_topk_device.argtypes = [C.c_int, vp, vp, sz, sz, sz, vp, vp, vp]
+    L.expann_score_ids.restype = C.c_int
+    L.expann_score_ids.argtypes = [vp, vp, vp, sz, C.c_float, vp, vp, C.POINTER(sz)]
+    L.expann_set_profiling.restype = C.c_int
+    L.expann_set_profiling.argtypes = [vp, C.c_int]
+    L.expann_get_profile.restype = C.c_int
+    L.expann_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.expann_set_option.restype = C.c_int
+    L.expann_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    _lib = L
+    return L
+
+
+def check(handle, rc):
+    if rc != OK:
+        msg = load().expann_last_error(handle)
+        raise ExpannError(rc, msg.decode() if msg else "")

@@ -1,0 +1,666 @@
+// expann_hip.hip -- the C ABI (include/expann_hip.h) over the gfx950 kernels.
+//
+// Host side of the hot path: owns device memory, plans the threshold levels, launches the
+// scan / select / merge kernels on HIP streams.  No CPU fallback lives here: every compute
+// entry point needs a HIP device and fails loudly without one.
+#include "../../include/expann_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "scan_f32.hpp"
+#include "score_ids.hpp"
+#include "select.hpp"
+
+using namespace expann;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t kMaxCap = 16384;      // keys per query that fit the select kernel's LDS
+constexpr size_t kMaxQueriesPerPass = 32768;
+constexpr int kEventPairs = 64;
+
+struct Level {
+	uint32_t n_groups_sel;
+	uint32_t group_stride;
+};
+
+}  // namespace
+
+struct expann_index {
+	int dim = 0, dtype = 0, metric = 0, device = 0;
+	size_t elem = 4;
+	std::vector<unsigned char> staging;  // store_vector() rows until build()
+	size_t n_staged = 0;
+	void* d_base = nullptr;
+	bool owns_base = false;
+	size_t n = 0;
+	uint64_t id_offset = 0;
+	hipStream_t stream = nullptr;
+	// workspace (grown on demand)
+	uint64_t* d_cand = nullptr;
+	size_t cand_elems = 0;
+	uint32_t* d_cnt = nullptr;       // [m] + overflow word + pad
+	float* d_tau[2] = {nullptr, nullptr};
+	size_t m_alloc = 0;
+	uint32_t* d_overflow = nullptr;  // [4]: overflow count
+	unsigned long long* d_total = nullptr;
+	uint32_t* h_flags = nullptr;     // pinned [4]
+	void* d_q = nullptr;             // host-API staging
+	uint64_t* d_ids = nullptr;
+	float* d_dists = nullptr;
+	size_t io_q_bytes = 0, io_out = 0;
+	// options
+	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
+	// profiling
+	bool profiling = false;
+	hipEvent_t ev[kEventPairs][2];
+	bool ev_created = false;
+	int ev_used = 0;
+	expann_profile prof{};
+	mutable std::string err;
+
+	int fail(int code, const std::string& msg) const {
+		err = msg;
+		return code;
+	}
+};
+
+#define HIP_TRY(h, expr)                                                                   \
+	do {                                                                                   \
+		hipError_t _e = (expr);                                                            \
+		if (_e != hipSuccess)                                                              \
+			return (h)->fail(EXPANN_ERR_HIP, std::string(#expr) + ": " +                   \
+			                                       hipGetErrorString(_e));                 \
+	} while (0)
+
+namespace {
+
+// ---- kernel dispatch ---------------------------------------------------------------
+using ScanFn = void (*)(ScanParams);
+struct ScanVariant {
+	int d, tq;
+	bool ip;
+	ScanFn fn;
+	const char* name;
+};
+#define SCAN_V(D, TQ)                                                                      \
+	{D, TQ, false, scan_filter_f32_kernel<D, TQ, false>, "scan_filter_f32<" #D "," #TQ ",L2>"}, \
+	{D, TQ, true, scan_filter_f32_kernel<D, TQ, true>, "scan_filter_f32<" #D "," #TQ ",IP>"}
+const ScanVariant kScanF32[] = {
+    SCAN_V(64, 1),  SCAN_V(64, 4),  SCAN_V(64, 16), SCAN_V(128, 1), SCAN_V(128, 2),
+    SCAN_V(128, 4), SCAN_V(128, 8), SCAN_V(128, 16), SCAN_V(256, 1), SCAN_V(256, 4),
+    SCAN_V(256, 8), SCAN_V(512, 1), SCAN_V(512, 4),  SCAN_V(768, 1), SCAN_V(768, 2),
+    SCAN_V(832, 1), SCAN_V(832, 2), SCAN_V(960, 1),  SCAN_V(960, 2), SCAN_V(1024, 1),
+    SCAN_V(1024, 2)};
+#undef SCAN_V
+
+const ScanVariant* pick_scan_f32(int d, bool ip, size_t m, long forced_tq) {
+	const ScanVariant* best = nullptr;
+	for (const auto& v : kScanF32) {
+		if (v.d != d || v.ip != ip)
+			continue;
+		if (forced_tq > 0) {
+			if (v.tq == forced_tq)
+				return &v;
+			continue;
+		}
+		if (!best) {
+			best = &v;
+			continue;
+		}
+		// smallest tile that covers m, else the largest tile
+		const bool v_covers = (size_t)v.tq >= m, b_covers = (size_t)best->tq >= m;
+		if (v_covers && (!b_covers || v.tq < best->tq))
+			best = &v;
+		else if (!v_covers && !b_covers && v.tq > best->tq)
+			best = &v;
+	}
+	return best;
+}
+
+using ScoreFn = void (*)(ScoreIdsParams);
+struct ScoreVariant {
+	int d;
+	bool ip;
+	ScoreFn fn;
+};
+#define SCORE_V(D) {D, false, score_ids_f32_kernel<D, false>}, {D, true, score_ids_f32_kernel<D, true>}
+const ScoreVariant kScoreF32[] = {SCORE_V(64),  SCORE_V(128), SCORE_V(256), SCORE_V(512),
+                                  SCORE_V(768), SCORE_V(832), SCORE_V(960), SCORE_V(1024)};
+#undef SCORE_V
+
+uint32_t pow2ceil(uint32_t x) {
+	uint32_t p = 1;
+	while (p < x)
+		p <<= 1;
+	return p;
+}
+
+int num_cus(int device) {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return 256;
+	return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+// Threshold levels: level 0 keeps every row of a small strided sample (tau = +inf), each
+// later level scans `ratio` times more rows with tau = k-th best score of the level before,
+// the last level scans every row.  Expected survivors per query and level ~ ratio * k.
+std::vector<Level> plan_levels(size_t n, size_t k, uint32_t cap, long ratio_opt) {
+	const uint32_t n_groups = (uint32_t)((n + kRowsPerGroup - 1) / kRowsPerGroup);
+	uint32_t s0 = std::max<uint32_t>(64, (uint32_t)((4 * k + kRowsPerGroup - 1) / kRowsPerGroup));
+	s0 = std::min(s0, cap / kRowsPerGroup);
+	std::vector<Level> lv;
+	if (n_groups <= s0) {
+		lv.push_back({n_groups, 1});
+		return lv;
+	}
+	// survivors ~ ratio*k must stay well inside cap
+	double max_ratio = std::max(2.0, (double)cap / (6.0 * (double)k));
+	double ratio = std::min<double>((double)ratio_opt, max_ratio);
+	if (ratio < 2.0)
+		ratio = 2.0;
+	const double span = (double)n_groups / (double)s0;
+	int steps = (int)std::ceil(std::log(span) / std::log(ratio) - 1e-9);
+	if (steps < 1)
+		steps = 1;
+	const double r = std::pow(span, 1.0 / steps);
+	double cur = s0;
+	lv.push_back({s0, n_groups / s0});
+	for (int i = 1; i < steps; ++i) {
+		cur *= r;
+		uint32_t sel = (uint32_t)std::llround(cur);
+		sel = std::min(sel, n_groups);
+		lv.push_back({sel, std::max<uint32_t>(1, n_groups / sel)});
+	}
+	lv.push_back({n_groups, 1});
+	return lv;
+}
+
+int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
+	if (m > h->m_alloc) {
+		if (h->d_cnt) hipFree(h->d_cnt);
+		if (h->d_tau[0]) hipFree(h->d_tau[0]);
+		if (h->d_tau[1]) hipFree(h->d_tau[1]);
+		h->d_cnt = nullptr;
+		h->d_tau[0] = h->d_tau[1] = nullptr;
+		HIP_TRY(h, hipMalloc(&h->d_cnt, sizeof(uint32_t) * m));
+		HIP_TRY(h, hipMalloc(&h->d_tau[0], sizeof(float) * m));
+		HIP_TRY(h, hipMalloc(&h->d_tau[1], sizeof(float) * m));
+		h->m_alloc = m;
+	}
+	const size_t need = m * (size_t)cap;
+	if (need > h->cand_elems) {
+		if (h->d_cand) hipFree(h->d_cand);
+		h->d_cand = nullptr;
+		h->cand_elems = 0;
+		HIP_TRY(h, hipMalloc(&h->d_cand, sizeof(uint64_t) * need));
+		h->cand_elems = need;
+	}
+	if (!h->d_overflow) {
+		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4));
+		HIP_TRY(h, hipMalloc(&h->d_total, sizeof(unsigned long long) * 2));
+		HIP_TRY(h, hipHostMalloc((void**)&h->h_flags, sizeof(uint32_t) * 8, 0));
+	}
+	return EXPANN_OK;
+}
+
+// One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
+int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
+                float* d_dists, hipStream_t st) {
+	const bool ip = (h->metric == EXPANN_METRIC_IP);
+	const ScanVariant* sv = pick_scan_f32(h->dim, ip, m, h->opt_query_tile);
+	if (!sv)
+		return h->fail(EXPANN_ERR_UNSUPPORTED,
+		               "no fp32 scan kernel for dim " + std::to_string(h->dim) +
+		                   " / query_tile " + std::to_string(h->opt_query_tile));
+	uint32_t cap = h->opt_cand_capacity > 0
+	                   ? (uint32_t)h->opt_cand_capacity
+	                   : pow2ceil((uint32_t)std::max<size_t>(2048, 64 * k));
+	cap = std::min(pow2ceil(cap), kMaxCap);
+	if ((size_t)cap < 2 * k)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "k too large for the candidate buffers (k <= " +
+		                                           std::to_string(kMaxCap / 2) + ")");
+	const int cus = num_cus(h->device);
+
+	for (int attempt = 0;; ++attempt) {
+		int rc = ensure_workspace(h, m, cap);
+		if (rc != EXPANN_OK)
+			return rc;
+		const std::vector<Level> levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
+		const uint32_t n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t) * 4, st));
+		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
+		for (size_t li = 0; li < levels.size(); ++li) {
+			const Level& L = levels[li];
+			const bool first = (li == 0), last = (li + 1 == levels.size());
+			ScanParams sp{};
+			sp.base = h->d_base;
+			sp.n_rows = (uint32_t)h->n;
+			sp.n_groups_sel = L.n_groups_sel;
+			sp.group_stride = L.group_stride;
+			sp.n_qtiles = n_qtiles;
+			sp.queries = d_queries;
+			sp.m = (uint32_t)m;
+			sp.tau = first ? nullptr : h->d_tau[(li + 1) & 1];
+			sp.cand_cnt = h->d_cnt;
+			sp.cand = h->d_cand;
+			sp.cap = cap;
+			// ~16 workgroups per CU in total, at least 8 groups (128 rows) per workgroup
+			uint32_t target_chunks = (uint32_t)std::max<long>(1, (16L * cus + n_qtiles - 1) / n_qtiles);
+			uint32_t max_chunks = std::max<uint32_t>(1, L.n_groups_sel / 8);
+			uint32_t n_chunks = std::min(target_chunks, max_chunks);
+			sp.groups_per_block = (L.n_groups_sel + n_chunks - 1) / n_chunks;
+			n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
+			if (!first)
+				HIP_TRY(h, hipMemsetAsync(h->d_cnt, 0, sizeof(uint32_t) * m, st));
+			const bool timed = last && h->profiling && h->ev_used < kEventPairs;
+			if (timed)
+				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+			hipLaunchKernelGGL(sv->fn, dim3(n_chunks * n_qtiles), dim3(kBlock), 0, st, sp);
+			if (timed) {
+				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
+				h->ev_used++;
+			}
+			if (last && (timed || !h->profiling)) {
+				h->prof.scan_launches++;
+				h->prof.scan_rows += h->n;
+				h->prof.scan_query_tiles += n_qtiles;
+				h->prof.query_tile = (uint32_t)sv->tq;
+				h->prof.levels = (uint32_t)levels.size();
+				std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", sv->name);
+			}
+			HIP_TRY(h, hipGetLastError());
+
+			SelectParams sel{};
+			sel.cand = h->d_cand;
+			sel.cand_cnt = first ? nullptr : h->d_cnt;
+			sel.fixed_count = L.n_groups_sel * kRowsPerGroup;
+			sel.cap = cap;
+			sel.k = (uint32_t)k;
+			sel.id_offset = h->id_offset;
+			sel.out_ids = last ? d_ids : nullptr;
+			sel.out_dists = last ? d_dists : nullptr;
+			sel.tau_out = last ? nullptr : h->d_tau[li & 1];
+			sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
+			sel.overflow = h->d_overflow;
+			sel.total_cand = last ? h->d_total : nullptr;
+			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
+			                   sizeof(uint64_t) * cap, st, sel);
+			HIP_TRY(h, hipGetLastError());
+		}
+		// overflow check (the only host sync of a search)
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4,
+		                          hipMemcpyDeviceToHost, st));
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags + 4, h->d_total, sizeof(unsigned long long),
+		                          hipMemcpyDeviceToHost, st));
+		HIP_TRY(h, hipStreamSynchronize(st));
+		unsigned long long tot;
+		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
+		h->prof.candidates = tot;
+		if (h->h_flags[0] == 0)
+			return EXPANN_OK;
+		// some candidate list overflowed: retry with 4x the capacity
+		h->prof.retries++;
+		if (cap >= kMaxCap || attempt >= 3)
+			return h->fail(EXPANN_ERR_OVERFLOW,
+			               "candidate lists overflowed (" + std::to_string(h->h_flags[0]) +
+			                   " queries) at capacity " + std::to_string(cap) +
+			                   "; the data has more near-ties than the threshold filter supports");
+		cap = std::min(cap * 4, kMaxCap);
+	}
+}
+
+}  // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------
+extern "C" {
+
+int expann_abi_version(void) { return EXPANN_ABI_VERSION; }
+
+int expann_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int expann_create(int dim, int dtype, int metric, int device, expann_index** out) {
+	if (!out) {
+		g_create_error = "out == NULL";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	*out = nullptr;
+	if (dim <= 0 || dim % 16 != 0) {
+		g_create_error = "dim must be a positive multiple of 16 (the reference kernels require it)";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (dtype != EXPANN_DTYPE_F32) {
+		g_create_error = "only EXPANN_DTYPE_F32 is implemented in this build";
+		return EXPANN_ERR_UNSUPPORTED;
+	}
+	if (metric != EXPANN_METRIC_L2 && metric != EXPANN_METRIC_IP) {
+		g_create_error = "metric must be EXPANN_METRIC_L2 or EXPANN_METRIC_IP for f32 rows";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	int ndev = expann_device_count();
+	if (ndev <= 0) {
+		g_create_error = "no HIP device visible: libexpann_hip has no CPU fallback";
+		return EXPANN_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= ndev) {
+		g_create_error = "device index out of range";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (!pick_scan_f32(dim, metric == EXPANN_METRIC_IP, 1, 0)) {
+		g_create_error = "unsupported dim " + std::to_string(dim) +
+		                 " (built: 64,128,256,512,768,832,960,1024)";
+		return EXPANN_ERR_UNSUPPORTED;
+	}
+	expann_index* h = new expann_index();
+	h->dim = dim;
+	h->dtype = dtype;
+	h->metric = metric;
+	h->device = device;
+	h->elem = 4;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+		g_create_error = "hipSetDevice/hipStreamCreate failed";
+		delete h;
+		return EXPANN_ERR_HIP;
+	}
+	// the select kernel sorts up to kMaxCap 8-byte keys in LDS (128 KiB of the CU's 160 KiB)
+	if (hipFuncSetAttribute((const void*)select_topk_kernel,
+	                        hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        (int)(sizeof(uint64_t) * kMaxCap)) != hipSuccess) {
+		g_create_error = "hipFuncSetAttribute(select_topk_kernel) failed";
+		hipStreamDestroy(h->stream);
+		delete h;
+		return EXPANN_ERR_HIP;
+	}
+	*out = h;
+	return EXPANN_OK;
+}
+
+void expann_destroy(expann_index* h) {
+	if (!h)
+		return;
+	hipSetDevice(h->device);
+	if (h->stream) hipStreamSynchronize(h->stream);
+	if (h->owns_base && h->d_base) hipFree(h->d_base);
+	if (h->d_cand) hipFree(h->d_cand);
+	if (h->d_cnt) hipFree(h->d_cnt);
+	if (h->d_tau[0]) hipFree(h->d_tau[0]);
+	if (h->d_tau[1]) hipFree(h->d_tau[1]);
+	if (h->d_overflow) hipFree(h->d_overflow);
+	if (h->d_total) hipFree(h->d_total);
+	if (h->h_flags) hipHostFree(h->h_flags);
+	if (h->d_q) hipFree(h->d_q);
+	if (h->d_ids) hipFree(h->d_ids);
+	if (h->d_dists) hipFree(h->d_dists);
+	if (h->ev_created)
+		for (int i = 0; i < kEventPairs; ++i) {
+			hipEventDestroy(h->ev[i][0]);
+			hipEventDestroy(h->ev[i][1]);
+		}
+	if (h->stream) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+const char* expann_last_error(const expann_index* h) {
+	return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int expann_add(expann_index* h, const void* rows, size_t n) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!rows && n)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "rows == NULL");
+	if (h->d_base)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "index already built");
+	const size_t bytes = n * (size_t)h->dim * h->elem;
+	const unsigned char* src = static_cast<const unsigned char*>(rows);
+	h->staging.insert(h->staging.end(), src, src + bytes);
+	h->n_staged += n;
+	return EXPANN_OK;
+}
+
+int expann_build(expann_index* h) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (h->d_base)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "index already built");
+	if (h->n_staged == 0)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "build() on an empty index");
+	if (h->n_staged >= (1ull << 32) - 32)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipMalloc(&h->d_base, h->staging.size()));
+	h->owns_base = true;
+	HIP_TRY(h, hipMemcpy(h->d_base, h->staging.data(), h->staging.size(), hipMemcpyHostToDevice));
+	h->n = h->n_staged;
+	std::vector<unsigned char>().swap(h->staging);
+	return EXPANN_OK;
+}
+
+int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64_t id_offset) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!d_rows || n == 0)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "empty device base");
+	if (n >= (1ull << 32) - 32)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+	if (h->owns_base && h->d_base)
+		hipFree(h->d_base);
+	h->d_base = const_cast<void*>(d_rows);
+	h->owns_base = false;
+	h->n = n;
+	h->id_offset = id_offset;
+	return EXPANN_OK;
+}
+
+size_t expann_size(const expann_index* h) { return h ? (h->d_base ? h->n : h->n_staged) : 0; }
+
+int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_t k,
+                         uint64_t* d_ids, float* d_dists, void* stream) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!h->d_base)
+		return h->fail(EXPANN_ERR_NOT_BUILT, "search before build()");
+	if (k == 0)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "k == 0");
+	if (m == 0)
+		return EXPANN_OK;
+	if (!d_queries || !d_ids)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+	const size_t qbytes = (size_t)h->dim * h->elem;
+	for (size_t q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
+		const size_t mm = std::min(kMaxQueriesPerPass, m - q0);
+		int rc = search_pass(h, (const char*)d_queries + q0 * qbytes, mm, k, d_ids + q0 * k,
+		                     d_dists ? d_dists + q0 * k : nullptr, st);
+		if (rc != EXPANN_OK)
+			return rc;
+	}
+	return EXPANN_OK;
+}
+
+int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint64_t* ids,
+                  float* dists) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!h->d_base)
+		return h->fail(EXPANN_ERR_NOT_BUILT, "search before build()");
+	if (k == 0)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "k == 0");
+	if (m == 0)
+		return EXPANN_OK;
+	if (!queries || !ids)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	const size_t qbytes = m * (size_t)h->dim * h->elem;
+	if (qbytes > h->io_q_bytes) {
+		if (h->d_q) hipFree(h->d_q);
+		h->d_q = nullptr;
+		h->io_q_bytes = 0;
+		HIP_TRY(h, hipMalloc(&h->d_q, qbytes));
+		h->io_q_bytes = qbytes;
+	}
+	if (m * k > h->io_out) {
+		if (h->d_ids) hipFree(h->d_ids);
+		if (h->d_dists) hipFree(h->d_dists);
+		h->d_ids = nullptr;
+		h->d_dists = nullptr;
+		h->io_out = 0;
+		HIP_TRY(h, hipMalloc(&h->d_ids, sizeof(uint64_t) * m * k));
+		HIP_TRY(h, hipMalloc(&h->d_dists, sizeof(float) * m * k));
+		h->io_out = m * k;
+	}
+	HIP_TRY(h, hipMemcpyAsync(h->d_q, queries, qbytes, hipMemcpyHostToDevice, h->stream));
+	int rc = expann_search_device(h, h->d_q, m, k, h->d_ids, h->d_dists, h->stream);
+	if (rc != EXPANN_OK)
+		return rc;
+	HIP_TRY(h, hipMemcpyAsync(ids, h->d_ids, sizeof(uint64_t) * m * k, hipMemcpyDeviceToHost,
+	                          h->stream));
+	if (dists)
+		HIP_TRY(h, hipMemcpyAsync(dists, h->d_dists, sizeof(float) * m * k,
+		                          hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return EXPANN_OK;
+}
+
+int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
+                             size_t n_lists, size_t m, size_t k, uint64_t* d_out_ids,
+                             float* d_out_dists, void* stream) {
+	if (!d_in_ids || !d_in_dists || !d_out_ids || !d_out_dists || n_lists == 0 || n_lists > 64 ||
+	    k == 0) {
+		g_create_error = "expann_merge_topk_device: bad arguments (1 <= n_lists <= 64)";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (m == 0)
+		return EXPANN_OK;
+	if (hipSetDevice(device) != hipSuccess) {
+		g_create_error = "hipSetDevice failed";
+		return EXPANN_ERR_HIP;
+	}
+	hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
+	                   dim3(kBlock), 0, (hipStream_t)stream, d_in_ids, d_in_dists,
+	                   (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids, d_out_dists);
+	if (hipGetLastError() != hipSuccess) {
+		g_create_error = "merge_topk_kernel launch failed";
+		return EXPANN_ERR_HIP;
+	}
+	return EXPANN_OK;
+}
+
+int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, size_t n_ids,
+                     float cutoff, uint64_t* kept_ids, float* kept_scores, size_t* n_kept) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!h->d_base)
+		return h->fail(EXPANN_ERR_NOT_BUILT, "score_ids before build()");
+	if (!n_kept || (n_ids && (!query || !ids || !kept_ids || !kept_scores)))
+		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL pointer");
+	*n_kept = 0;
+	if (n_ids == 0)
+		return EXPANN_OK;
+	for (size_t i = 0; i < n_ids; ++i)
+		if (ids[i] < h->id_offset || ids[i] - h->id_offset >= h->n)
+			return h->fail(EXPANN_ERR_INVALID_ARG, "id out of range");
+	HIP_TRY(h, hipSetDevice(h->device));
+	const ScoreVariant* sv = nullptr;
+	for (const auto& v : kScoreF32)
+		if (v.d == h->dim && v.ip == (h->metric == EXPANN_METRIC_IP))
+			sv = &v;
+	if (!sv)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "no score kernel for this dim");
+	void *d_query = nullptr, *d_idl = nullptr, *d_sc = nullptr;
+	const size_t qb = (size_t)h->dim * h->elem;
+	HIP_TRY(h, hipMalloc(&d_query, qb));
+	HIP_TRY(h, hipMalloc(&d_idl, sizeof(uint64_t) * n_ids));
+	HIP_TRY(h, hipMalloc(&d_sc, sizeof(float) * n_ids));
+	HIP_TRY(h, hipMemcpyAsync(d_query, query, qb, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(d_idl, ids, sizeof(uint64_t) * n_ids, hipMemcpyHostToDevice, h->stream));
+	ScoreIdsParams sp{h->d_base, d_query, (const uint64_t*)d_idl, h->id_offset, (uint32_t)n_ids,
+	                  (float*)d_sc};
+	const uint32_t blocks = (uint32_t)((n_ids + kRowsPerGroup - 1) / kRowsPerGroup);
+	hipLaunchKernelGGL(sv->fn, dim3(blocks), dim3(kBlock), 0, h->stream, sp);
+	HIP_TRY(h, hipGetLastError());
+	std::vector<float> sc(n_ids);
+	HIP_TRY(h, hipMemcpyAsync(sc.data(), d_sc, sizeof(float) * n_ids, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	hipFree(d_query);
+	hipFree(d_idl);
+	hipFree(d_sc);
+	size_t kept = 0;
+	for (size_t i = 0; i < n_ids; ++i)  // src/quantizer.h:42-46: keep iff d < cutoff, order kept
+		if (sc[i] < cutoff) {
+			kept_ids[kept] = ids[i];
+			kept_scores[kept] = sc[i];
+			++kept;
+		}
+	*n_kept = kept;
+	return EXPANN_OK;
+}
+
+int expann_set_profiling(expann_index* h, int enable) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	HIP_TRY(h, hipSetDevice(h->device));
+	if (enable && !h->ev_created) {
+		for (int i = 0; i < kEventPairs; ++i) {
+			HIP_TRY(h, hipEventCreate(&h->ev[i][0]));
+			HIP_TRY(h, hipEventCreate(&h->ev[i][1]));
+		}
+		h->ev_created = true;
+	}
+	h->profiling = enable != 0;
+	h->ev_used = 0;
+	h->prof = expann_profile{};
+	return EXPANN_OK;
+}
+
+int expann_get_profile(expann_index* h, expann_profile* out) {
+	if (!h || !out)
+		return EXPANN_ERR_INVALID_ARG;
+	HIP_TRY(h, hipSetDevice(h->device));
+	double ms = 0;
+	for (int i = 0; i < h->ev_used; ++i) {
+		HIP_TRY(h, hipEventSynchronize(h->ev[i][1]));
+		float t = 0;
+		HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i][0], h->ev[i][1]));
+		ms += t;
+	}
+	h->prof.scan_ms = ms;
+	// (launches beyond the event pool are neither timed nor counted while profiling)
+	*out = h->prof;
+	h->ev_used = 0;
+	h->prof = expann_profile{};
+	return EXPANN_OK;
+}
+
+int expann_set_option(expann_index* h, const char* name, long value) {
+	if (!h || !name)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!std::strcmp(name, "query_tile"))
+		h->opt_query_tile = value;
+	else if (!std::strcmp(name, "cand_capacity"))
+		h->opt_cand_capacity = value;
+	else if (!std::strcmp(name, "sample_ratio"))
+		h->opt_sample_ratio = value < 2 ? 2 : value;
+	else
+		return h->fail(EXPANN_ERR_INVALID_ARG, std::string("unknown option ") + name);
+	return EXPANN_OK;
+}
+
+}  // extern "C"

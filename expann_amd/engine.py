@@ -1,0 +1,130 @@
+"""Host-side mirror (Python) of the reference's engine interface for the brute-force path.
+
+`GpuBruteForceEngine` has the five operations of the reference's CRTP `ann_engine`
+(upstream src/ann_engine.h:16-29: name / param_list / store_vector / build / query_k) with
+the meaning `brute_force_engine` gives them (src/brute_force_engine.h:9-46), plus the batch
+and device-pointer extensions the GPU path needs.  All compute goes through the C ABI
+(include/expann_hip.h); this module only moves pointers.  The C++ mirror a maintainer would
+drop into the reference tree is include/expann/gpu_brute_force_engine.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_NP_DTYPE = {_lib.DTYPE_F32: np.float32, _lib.DTYPE_U8: np.uint8, _lib.DTYPE_I8: np.int8}
+
+
+class GpuBruteForceEngine:
+    """Exact k-NN by a full scan on one MI355X (drop-in for brute_force_engine<float>)."""
+
+    def __init__(self, dim, metric="l2", dtype="f32", device=0):
+        self._L = _lib.load()
+        self.dim = int(dim)
+        self.metric = {"l2": _lib.METRIC_L2, "ip": _lib.METRIC_IP,
+                       "l2_i8_refcompat": _lib.METRIC_L2_I8_REFCOMPAT}[metric]
+        self.dtype = {"f32": _lib.DTYPE_F32, "u8": _lib.DTYPE_U8, "i8": _lib.DTYPE_I8}[dtype]
+        self.device = int(device)
+        self._metric_name, self._dtype_name = metric, dtype
+        h = C.c_void_p()
+        rc = self._L.expann_create(self.dim, self.dtype, self.metric, self.device, C.byref(h))
+        _lib.check(None, rc)
+        self._h = h
+
+    # ---- the reference interface (src/ann_engine.h:16-29) ---------------------------
+    def name(self):
+        return "GPU Brute-Force Engine (MI355X)"
+
+    def param_list(self):
+        return {"device": str(self.device), "metric": self._metric_name, "dtype": self._dtype_name}
+
+    def store_vector(self, v):
+        """src/brute_force_engine.h:20-22: copies one row; ids are insertion order."""
+        self.store_many_vectors(np.asarray(v).reshape(1, -1))
+
+    def store_many_vectors(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=_NP_DTYPE[self.dtype])
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}]")
+        _lib.check(self._h, self._L.expann_add(self._h, rows.ctypes.data, rows.shape[0]))
+
+    def build(self):
+        """src/brute_force_engine.h:24-26 (asserts a non-empty index): upload to HBM."""
+        _lib.check(self._h, self._L.expann_build(self._h))
+
+    def query_k(self, v, k):
+        """src/brute_force_engine.h:28-46: ids of the min(k, n) nearest rows, ascending."""
+        ids, _ = self.query_k_batch(np.asarray(v).reshape(1, -1), k)
+        row = ids[0]
+        return [int(x) for x in row[row != np.uint64(2 ** 64 - 1)]]
+
+    # ---- extensions ---------------------------------------------------------------
+    def query_k_batch(self, queries, k):
+        """(ids[m,k] uint64, dists[m,k] float32); short rows padded with 2^64-1 / +inf."""
+        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else np.int8
+        queries = np.ascontiguousarray(queries, dtype=qdt)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise ValueError(f"queries must be [m, {self.dim}]")
+        m = queries.shape[0]
+        ids = np.empty((m, k), dtype=np.uint64)
+        dists = np.empty((m, k), dtype=np.float32)
+        _lib.check(self._h, self._L.expann_search(self._h, queries.ctypes.data, m, k,
+                                                  ids.ctypes.data, dists.ctypes.data))
+        return ids, dists
+
+    def set_base_device(self, ptr, n, id_offset=0):
+        _lib.check(self._h, self._L.expann_set_base_device(self._h, C.c_void_p(ptr), n, id_offset))
+
+    def search_device(self, q_ptr, m, k, ids_ptr, dists_ptr, stream=0):
+        _lib.check(self._h, self._L.expann_search_device(
+            self._h, C.c_void_p(q_ptr), m, k, C.c_void_p(ids_ptr), C.c_void_p(dists_ptr),
+            C.c_void_p(stream)))
+
+    def score_ids(self, query, ids, cutoff=float("inf")):
+        """quantized_scorer::filter_by_score (src/quantizer.h:20-59): (kept_ids, kept_scores)."""
+        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else np.int8
+        query = np.ascontiguousarray(query, dtype=qdt)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        kept = np.empty(ids.size, dtype=np.uint64)
+        sc = np.empty(ids.size, dtype=np.float32)
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.expann_score_ids(self._h, query.ctypes.data, ids.ctypes.data,
+                                                     ids.size, cutoff, kept.ctypes.data,
+                                                     sc.ctypes.data, C.byref(n)))
+        return kept[:n.value], sc[:n.value]
+
+    def set_option(self, name, value):
+        _lib.check(self._h, self._L.expann_set_option(self._h, name.encode(), int(value)))
+
+    def set_profiling(self, enable=True):
+        _lib.check(self._h, self._L.expann_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self):
+        p = _lib.Profile()
+        _lib.check(self._h, self._L.expann_get_profile(self._h, C.byref(p)))
+        return {f: (getattr(p, f).decode() if f == "scan_kernel" else getattr(p, f))
+                for f, _ in _lib.Profile._fields_}
+
+    def size(self):
+        return self._L.expann_size(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.expann_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_device(device, in_ids_ptr, in_dists_ptr, n_lists, m, k, out_ids_ptr,
+                      out_dists_ptr, stream=0):
+    L = _lib.load()
+    rc = L.expann_merge_topk_device(device, C.c_void_p(in_ids_ptr), C.c_void_p(in_dists_ptr),
+                                    n_lists, m, k, C.c_void_p(out_ids_ptr),
+                                    C.c_void_p(out_dists_ptr), C.c_void_p(stream))
+    _lib.check(None, rc)

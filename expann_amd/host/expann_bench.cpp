@@ -1,0 +1,145 @@
+// expann_bench.cpp -- thin host driver: the counterpart of the reference's CLI
+// (upstream src/main.cpp:32-109) for the brute-force path.  It accepts the same config
+// JSON keys (dataset, ds_name, num_threads, k and n, m, d for "Synthetic",
+// config_synthetic.json:1-9) with the same precedence CLI `--name value` > config file
+// (src/main.cpp:32-50), generates the synthetic dataset the way the reference does
+// (iid N(0,1) per component, un-normalised: src/randomgeometry.h:87-95; ground truth by
+// exact brute force: src/dataset_loader.h:27-38) and prints one bench_data JSON per run
+// mode with the reference's field names (src/bench_data.h:20-28).
+//
+// Differences, all deliberate: the dimension is a run-time value (the reference bakes
+// -DDIM into the binary, CMakeLists.txt:87); the random seed is fixed (1234) instead of
+// std::random_device; Sift1M needs *.fvecs files that are not shipped (use --dataset
+// Synthetic); results go to stdout (and --out FILE) instead of ./data/<ds_name>/.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+
+#include "expann/basic_bench.h"
+#include "expann/gpu_brute_force_engine.h"
+
+// flat JSON object of string / number values -> map<string,string>
+static std::map<std::string, std::string> parse_flat_json(const std::string& text) {
+	std::map<std::string, std::string> out;
+	size_t i = 0;
+	auto skip = [&]() { while (i < text.size() && strchr(" \t\r\n,:{}", text[i])) ++i; };
+	auto token = [&]() -> std::string {
+		std::string t;
+		if (text[i] == '"') {
+			for (++i; i < text.size() && text[i] != '"'; ++i) t += text[i];
+			++i;
+		} else {
+			for (; i < text.size() && !strchr(" \t\r\n,:{}", text[i]); ++i) t += text[i];
+		}
+		return t;
+	};
+	for (;;) {
+		skip();
+		if (i >= text.size()) break;
+		std::string k = token();
+		skip();
+		if (i >= text.size()) break;
+		out[k] = token();
+	}
+	return out;
+}
+
+int main(int argc, char** argv) {
+	std::map<std::string, std::string> cli, cfg;
+	for (int a = 1; a + 1 < argc; a += 2) {
+		if (strncmp(argv[a], "--", 2) != 0) {
+			std::fprintf(stderr, "expected --name value, got %s\n", argv[a]);
+			return 2;
+		}
+		cli[argv[a] + 2] = argv[a + 1];
+	}
+	std::string config_file = cli.count("config") ? cli["config"] : "config.json";
+	{
+		std::ifstream f(config_file);
+		if (f) {
+			std::stringstream ss;
+			ss << f.rdbuf();
+			cfg = parse_flat_json(ss.str());
+		} else if (cli.count("config")) {
+			std::fprintf(stderr, "cannot open config %s\n", config_file.c_str());
+			return 2;
+		}
+	}
+	auto get = [&](const char* name, const char* dflt) -> std::string {
+		if (cli.count(name)) return cli[name];
+		if (cfg.count(name)) return cfg[name];
+		if (dflt) return dflt;
+		std::fprintf(stderr, "missing parameter %s (give --%s or put it in the config)\n", name, name);
+		std::exit(2);
+	};
+	const std::string dataset = get("dataset", "Synthetic");
+	if (dataset != "Synthetic") {
+		std::fprintf(stderr, "dataset %s needs *.fvecs files that are not shipped; only "
+		                     "\"Synthetic\" is wired in this driver\n", dataset.c_str());
+		return 2;
+	}
+	dense_test_dataset<float> ds;
+	ds.n = std::stoul(get("n", nullptr));
+	ds.m = std::stoul(get("m", nullptr));
+	ds.dim = std::stoul(get("d", nullptr));
+	ds.k = std::stoul(get("k", nullptr));
+	ds.name = get("ds_name", "synthetic");
+	const int device = std::stoi(get("device", "0"));
+	const std::string mode = get("mode", "both");  // serial | batched | both
+
+	std::mt19937 gen(1234);
+	std::normal_distribution<> nd(0, 1);
+	ds.all_vecs.resize(ds.n * ds.dim);
+	ds.all_query_vecs.resize(ds.m * ds.dim);
+	for (auto& x : ds.all_vecs) x = float(nd(gen));
+	for (auto& x : ds.all_query_vecs) x = float(nd(gen));
+
+	try {
+		{  // ground truth = exact brute force (src/dataset_loader.h:27-38), on the GPU
+			gpu_brute_force_engine<float> gt(gpu_brute_force_engine<float>::config(device));
+			gt.store_rows(ds.all_vecs.data(), ds.n, ds.dim);
+			gt.build();
+			std::vector<uint64_t> ids(ds.m * ds.k);
+			gt.query_k_batch(ds.all_query_vecs.data(), ds.m, ds.k, ids.data(), nullptr);
+			unsigned long long checksum = 1469598103934665603ull;  // FNV-1a over the ids
+			for (size_t q = 0; q < ds.m; ++q) {
+				std::vector<size_t> ans;
+				for (size_t i = 0; i < ds.k; ++i) {
+					uint64_t id = ids[q * ds.k + i];
+					checksum = (checksum ^ id) * 1099511628211ull;
+					if (id != UINT64_MAX) ans.push_back(size_t(id));
+				}
+				ds.all_query_ans.push_back(ans);
+			}
+			std::printf("{\"ground_truth_ids_fnv1a\":\"%016llx\",\"n\":%zu,\"m\":%zu,\"d\":%zu,\"k\":%zu}\n",
+			            checksum, ds.n, ds.m, ds.dim, ds.k);
+		}
+		basic_bench<float, dense_test_dataset<float>> bench(ds);
+		std::ofstream out;
+		if (cli.count("out")) out.open(cli["out"]);
+		if (mode == "serial" || mode == "both") {
+			gpu_brute_force_engine<float> eng(gpu_brute_force_engine<float>::config(device));
+			bench_data bd = bench.get_benchmark_data(eng);
+			bd.param_list["mode"] = "serial";
+			std::printf("%s\n", bd.to_string().c_str());
+			if (out) out << bd.to_string() << "\n";
+		}
+		if (mode == "batched" || mode == "both") {
+			gpu_brute_force_engine<float> eng(gpu_brute_force_engine<float>::config(device));
+			bench_data bd = bench.get_benchmark_data_batched(eng);
+			bd.param_list["mode"] = "batched";
+			std::printf("%s\n", bd.to_string().c_str());
+			if (out) out << bd.to_string() << "\n";
+		}
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return 1;
+	}
+	return 0;
+}

@@ -1,0 +1,133 @@
+/*
+ * expann_hip.h -- C ABI of the MI355X-native distance + top-k engine (libexpann_hip.so).
+ *
+ * This is the drop-in boundary for expANN's hot path: the entry points are what a C++
+ * engine class satisfying the reference's CRTP `ann_engine<T, Derived>` interface
+ * (upstream src/ann_engine.h:16-29) binds to.  Plain pointers and sizes only; no C++
+ * types, no exceptions, no torch types cross this boundary.  Every call returns an int
+ * status (EXPANN_OK == 0); the message of the last failure on a handle is available from
+ * expann_last_error().  A handle is single-caller; distinct handles may be used from
+ * different host threads concurrently (the reference runs one private engine per job
+ * thread, src/bench_runner.h:30-57,78-87).
+ *
+ * There is no CPU fallback behind this ABI: without a usable HIP device every compute
+ * entry point fails with EXPANN_ERR_NO_DEVICE.
+ */
+#ifndef EXPANN_HIP_H
+#define EXPANN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXPANN_ABI_VERSION 1
+
+enum expann_status {
+	EXPANN_OK = 0,
+	EXPANN_ERR_INVALID_ARG = 1,
+	EXPANN_ERR_NO_DEVICE = 2,
+	EXPANN_ERR_HIP = 3,
+	EXPANN_ERR_NOT_BUILT = 4,
+	EXPANN_ERR_UNSUPPORTED = 5,
+	EXPANN_ERR_OVERFLOW = 6 /* internal candidate buffers exhausted even after retries */
+};
+
+/* element type of the stored rows */
+enum expann_dtype {
+	EXPANN_DTYPE_F32 = 0, /* vec<float> rows, src/vec.h:17-23                         */
+	EXPANN_DTYPE_U8 = 1,  /* quantizer_simple<uint8_t> rows, src/quantizer.h:127      */
+	EXPANN_DTYPE_I8 = 2   /* quantizer_ranged_q8 rows, src/quantizer.h:152-238        */
+};
+
+/* how a (query, row) pair is scored; smaller score = nearer */
+enum expann_metric {
+	EXPANN_METRIC_L2 = 0, /* f32: squared L2 in the lane order of src/distance.h:136-147;
+	                         u8: src/antitopo_engine.h:38-61 (dist2_compressed);
+	                         i8: true sum (a-b)^2                                      */
+	EXPANN_METRIC_IP = 1, /* score = -dot (src/distance.h:181-190 for f32); largest
+	                         inner product first, ties by lower id                      */
+	EXPANN_METRIC_L2_I8_REFCOMPAT = 2 /* i8 only: src/distance.h:29-53 bit for bit,
+	                         including its zero-extension of the wrapped difference     */
+};
+
+typedef struct expann_index expann_index;
+
+/* library / device ------------------------------------------------------------------ */
+int expann_abi_version(void);
+/* number of visible HIP devices (0 when there is none or the runtime is unusable). */
+int expann_device_count(void);
+
+/* lifecycle (replaces: engine construction, src/bench_runner.h:33) -------------------- */
+int expann_create(int dim, int dtype, int metric, int device, expann_index** out);
+void expann_destroy(expann_index* h);
+/* message of the last error on h (or of the last failed expann_create when h == NULL). */
+const char* expann_last_error(const expann_index* h);
+
+/* store_vector x n (src/ann_engine.h:23-25, src/brute_force_engine.h:20-22): rows are
+ * COPIED into host staging; the caller keeps ownership.  Row i of the j-th call gets id
+ * (rows stored so far) + i, i.e. insertion order, like all_entries.push_back. */
+int expann_add(expann_index* h, const void* rows, size_t n);
+
+/* build() (src/ann_engine.h:26, src/brute_force_engine.h:24-26): upload the staged rows
+ * to HBM.  Fails with EXPANN_ERR_INVALID_ARG on an empty index (the reference asserts). */
+int expann_build(expann_index* h);
+
+/* Adopt rows that already live in device memory (no copy; the caller keeps them alive
+ * until expann_destroy).  id_offset is added to every returned id: rank r of a sharded
+ * job passes the global number of its first row.  Replaces add+build. */
+int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64_t id_offset);
+
+size_t expann_size(const expann_index* h);
+
+/* query_k for a batch (src/ann_engine.h:27-29, src/brute_force_engine.h:28-46; the
+ * reference has no batch API -- m = 1 is query_k).  Host buffers.  For each query the k
+ * rows with the smallest (score, id), ascending; ids[m][k], dists[m][k] (dists may be
+ * NULL).  When fewer than k rows exist the tail is padded with UINT64_MAX / +inf. */
+int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint64_t* ids,
+                  float* dists);
+
+/* same with device-resident queries and outputs, enqueued on `stream` (a hipStream_t;
+ * NULL = the index's own stream).  Asynchronous unless the call reports an error. */
+int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_t k,
+                         uint64_t* d_ids, float* d_dists, void* stream);
+
+/* k-way merge of per-shard results after an all-gather (RCCL): in_ids/in_dists are
+ * [n_lists][m][k], each row ascending by (score, id) and padded as above; out is [m][k]. */
+int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
+                             size_t n_lists, size_t m, size_t k, uint64_t* d_out_ids,
+                             float* d_out_dists, void* stream);
+
+/* batched candidate scoring (quantized_scorer::filter_by_score, src/quantizer.h:20-59):
+ * for each of n_ids row ids (order kept) score against ONE query; keep (id, score) with
+ * score < cutoff.  Host buffers; *n_kept receives the count. */
+int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, size_t n_ids,
+                     float cutoff, uint64_t* kept_ids, float* kept_scores, size_t* n_kept);
+
+/* profiling ------------------------------------------------------------------------- */
+typedef struct expann_profile {
+	uint64_t scan_launches;   /* launches of the full-base scan kernel since reset      */
+	double scan_ms;           /* their summed device time (HIP events on their stream)  */
+	uint64_t scan_rows;       /* rows streamed by those launches (per launch: n)        */
+	uint64_t scan_query_tiles;/* query tiles (passes over the base) by those launches   */
+	uint32_t query_tile;      /* Q_t: queries per pass of the last launch               */
+	uint32_t levels;          /* threshold levels of the last search                    */
+	uint64_t candidates;      /* candidates kept by the last full scan (all queries)    */
+	uint64_t retries;         /* overflow retries since reset                           */
+	char scan_kernel[64];     /* name of the full-scan kernel last launched             */
+} expann_profile;
+/* enable != 0 brackets every full-scan launch with HIP events. */
+int expann_set_profiling(expann_index* h, int enable);
+/* synchronises the recorded events, fills *out and resets the accumulators. */
+int expann_get_profile(expann_index* h, expann_profile* out);
+
+/* integer options: "query_tile" (0 = auto), "cand_capacity" (0 = auto),
+ * "sample_ratio" (rows ratio between threshold levels, default 32). */
+int expann_set_option(expann_index* h, const char* name, long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
