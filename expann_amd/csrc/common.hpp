@@ -10,6 +10,40 @@ constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kRowsPerWaveStep = 4;  // 16 lanes per row (the reference's 16 accumulators)
 constexpr int kRowsPerGroup = 16;    // one workgroup step = 4 waves x 4 rows
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- packed fp32 (VOP3P) helpers ----------------------------------------------------
+// Plain fp32 VALU ops issue at 16 lanes/clk per SIMD on gfx950 (measured: a wave64
+// v_fma_f32 costs 4 cycles at any occupancy); v_pk_*_f32 do two IEEE ops per lane in the
+// same 4 cycles.  hipcc scalarises <2 x float> arithmetic in the unrolled scan loops, so the
+// packed instructions are spelled out.  Each half is exactly the scalar op (same rounding),
+// so results stay bit-identical.  `sel` picks which half of the 64-bit register pair `r`
+// is broadcast to both halves (0 = low dword, 1 = high dword).
+template <int SEL> __device__ inline f32x2 pk_sub_bcast(f32x2 a, f32x2 r) {  // a - {r[SEL], r[SEL]}
+	f32x2 d;
+	if (SEL == 0)
+		asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+		    : "=v"(d) : "v"(a), "v"(r));
+	else
+		asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]"
+		    : "=v"(d) : "v"(a), "v"(r));
+	return d;
+}
+__device__ inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {  // {fma(a.x,b.x,c.x), fma(a.y,b.y,c.y)}
+	f32x2 d;
+	asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+template <int SEL> __device__ inline f32x2 pk_fma_bcast(f32x2 a, f32x2 r, f32x2 c) {  // fma(a, {r[SEL]..}, c)
+	f32x2 d;
+	if (SEL == 0)
+		asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(r), "v"(c));
+	else
+		asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+		    : "=v"(d) : "v"(a), "v"(r), "v"(c));
+	return d;
+}
+
 constexpr uint64_t kSentinelKey = ~0ull;  // sorts after every real (score, id) key
 
 // Monotone map float -> uint32: a < b  <=>  ord(a) < ord(b) for all non-NaN floats

@@ -38,8 +38,9 @@ struct ScanParams {
 
 template <int D, int TQ, bool IP>
 __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
-	static_assert(D % 16 == 0, "the reference kernels need dim % 16 == 0");
+	static_assert(D % 32 == 0, "the reference kernels need dim % 16 == 0");
 	constexpr int DPL = D / 16;  // dims per lane
+	constexpr int NP = (TQ + 1) / 2;  // query pairs
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int l = lane & 15, rg = lane >> 4;
@@ -50,17 +51,27 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 	const float* __restrict__ queries = (const float*)p.queries;
 	const bool level0 = (p.tau == nullptr);
 
-	// query slices -> VGPRs, thresholds -> SGPRs.  Slots past m never match (tau = -inf).
-	float q[TQ][DPL];
+	// query slices -> VGPRs (two queries per register pair, so the per-dim work is packed
+	// v_pk_add_f32 / v_pk_fma_f32: plain fp32 VALU ops issue at 16 lanes/clk on this chip,
+	// packed ones at 2 x 16), thresholds -> SGPRs.  Slots past m never match (tau = -inf).
+	f32x2 q2[NP][DPL];
 	float tau[TQ];
+#pragma unroll
+	for (int pq = 0; pq < NP; ++pq) {
+		const uint32_t qa = (q0 + 2 * pq < p.m) ? q0 + 2 * pq : p.m - 1;
+		const uint32_t qb = (q0 + 2 * pq + 1 < p.m) ? q0 + 2 * pq + 1 : p.m - 1;
+#pragma unroll
+		for (int t = 0; t < DPL; ++t)
+			q2[pq][t] = f32x2{queries[(size_t)qa * D + l + 16 * t],
+			                  queries[(size_t)qb * D + l + 16 * t]};
+	}
 #pragma unroll
 	for (int j = 0; j < TQ; ++j) {
 		const uint32_t qi = (q0 + j < p.m) ? q0 + j : p.m - 1;
-#pragma unroll
-		for (int t = 0; t < DPL; ++t)
-			q[j][t] = queries[(size_t)qi * D + l + 16 * t];
 		float tj = level0 ? __builtin_inff() : p.tau[qi];
-		tau[j] = (q0 + j < p.m) ? tj : -__builtin_inff();
+		tj = (q0 + j < p.m) ? tj : -__builtin_inff();
+		tau[j] = __builtin_bit_cast(float,
+		                            __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tj)));
 	}
 
 	const uint32_t g0 = chunk * p.groups_per_block;
@@ -71,33 +82,52 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 	auto row_of = [&](uint32_t g) -> uint32_t {
 		return g * p.group_stride * kRowsPerGroup + wave * kRowsPerWaveStep + rg;
 	};
-	auto load_row = [&](float (&r)[DPL], uint32_t row) {
+	// a lane's dims t and t+1 share one 64-bit register pair (op_sel picks the half)
+	auto load_row = [&](f32x2 (&r)[DPL / 2], uint32_t row) {
 		const uint32_t rr = row < p.n_rows ? row : p.n_rows - 1;
 		const float* src = base + (size_t)rr * D + l;
 #pragma unroll
-		for (int t = 0; t < DPL; ++t)
-			r[t] = src[16 * t];
+		for (int t = 0; t < DPL; t += 2)
+			r[t / 2] = f32x2{src[16 * t], src[16 * t + 16]};
 	};
-	auto process = [&](const float (&r)[DPL], uint32_t g) {
+	auto process = [&](const f32x2 (&r)[DPL / 2], uint32_t g) {
 		const uint32_t row = row_of(g);
 		const bool rvalid = row < p.n_rows;
-		float s[TQ];
-		bool any = false;
+		// per-pair accumulators; each component is one (row, query) chain of the reference:
+		// acc = fma(diff, diff, acc) over this lane's dims in increasing order
+		f32x2 acc[NP];
+		const f32x2 zero = f32x2{0.0f, 0.0f};
 #pragma unroll
-		for (int j = 0; j < TQ; ++j) {
-			float acc = 0.0f;
+		for (int pq = 0; pq < NP; ++pq)
+			acc[pq] = zero;
 #pragma unroll
-			for (int t = 0; t < DPL; ++t) {
+		for (int t = 0; t < DPL; t += 2) {
+#pragma unroll
+			for (int pq = 0; pq < NP; ++pq) {
 				if (IP) {
-					acc = __builtin_fmaf(q[j][t], r[t], acc);
+					acc[pq] = pk_fma_bcast<0>(q2[pq][t], r[t / 2], acc[pq]);
 				} else {
-					const float diff = q[j][t] - r[t];
-					acc = __builtin_fmaf(diff, diff, acc);
+					const f32x2 diff = pk_sub_bcast<0>(q2[pq][t], r[t / 2]);
+					acc[pq] = pk_fma(diff, diff, acc[pq]);
 				}
 			}
-			acc = reduce16_ref_order(acc);
-			s[j] = IP ? -acc : acc;
-			any |= (s[j] <= tau[j]);
+#pragma unroll
+			for (int pq = 0; pq < NP; ++pq) {
+				if (IP) {
+					acc[pq] = pk_fma_bcast<1>(q2[pq][t + 1], r[t / 2], acc[pq]);
+				} else {
+					const f32x2 diff = pk_sub_bcast<1>(q2[pq][t + 1], r[t / 2]);
+					acc[pq] = pk_fma(diff, diff, acc[pq]);
+				}
+			}
+		}
+		float s[TQ];
+		unsigned long long any = 0;
+#pragma unroll
+		for (int j = 0; j < TQ; ++j) {
+			const float red = reduce16_ref_order(acc[j >> 1][j & 1]);
+			s[j] = IP ? -red : red;
+			any |= __builtin_amdgcn_ballot_w64(s[j] <= tau[j]);
 		}
 		if (level0) {
 			// keep every row of the sample at its sample position (no atomics)
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 	};
 
 	// two row buffers: the loads of step g+1 / g+2 are in flight while step g computes
-	float ra[DPL], rb[DPL];
+	f32x2 ra[DPL / 2], rb[DPL / 2];
 	uint32_t g = g0;
 	if (g < g1)
 		load_row(ra, row_of(g));

@@ -102,7 +102,8 @@ int main(int argc, char** argv) {
 
 	try {
 		{  // ground truth = exact brute force (src/dataset_loader.h:27-38), on the GPU
-			gpu_brute_force_engine<float> gt(gpu_brute_force_engine<float>::config(device));
+			gpu_brute_force_engine<float>::config gcfg(device);
+			gpu_brute_force_engine<float> gt(gcfg);
 			gt.store_rows(ds.all_vecs.data(), ds.n, ds.dim);
 			gt.build();
 			std::vector<uint64_t> ids(ds.m * ds.k);
@@ -124,14 +125,16 @@ int main(int argc, char** argv) {
 		std::ofstream out;
 		if (cli.count("out")) out.open(cli["out"]);
 		if (mode == "serial" || mode == "both") {
-			gpu_brute_force_engine<float> eng(gpu_brute_force_engine<float>::config(device));
+			gpu_brute_force_engine<float>::config ecfg(device);
+			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data(eng);
 			bd.param_list["mode"] = "serial";
 			std::printf("%s\n", bd.to_string().c_str());
 			if (out) out << bd.to_string() << "\n";
 		}
 		if (mode == "batched" || mode == "both") {
-			gpu_brute_force_engine<float> eng(gpu_brute_force_engine<float>::config(device));
+			gpu_brute_force_engine<float>::config ecfg(device);
+			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data_batched(eng);
 			bd.param_list["mode"] = "batched";
 			std::printf("%s\n", bd.to_string().c_str());

@@ -65,6 +65,7 @@ template <typename T, typename test_dataset_t> struct basic_bench {
 	explicit basic_bench(const test_dataset_t& _ds) : ds(_ds) {}
 
 	template <class Engine> bench_data get_benchmark_data(ann_engine<T, Engine>& eng) const {
+		// (takes the CRTP base like src/basic_bench.h:58-59)
 		bench_data ret;
 		using clk = std::chrono::high_resolution_clock;
 		auto b0 = clk::now();

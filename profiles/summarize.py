@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py <tag> -- condense gpurun_out/prof_<tag>/ (raw rocprofv3 CSVs written
+by profiles/run_rocprof.sh) into the small files committed under profiles/:
+
+  <tag>_kernel_stats_<run>.csv   rocprofv3 --kernel-trace --stats summary (names shortened)
+  <tag>_summary.json             per-kernel average duration and HBM traffic per launch
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE come from separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports
+half the bytes of a streaming read -- calibrated here on the m=1 run, whose single pass over
+the 512 MB base (twice the 256 MiB Infinity Cache) must fetch N*d*4 bytes from HBM.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    if "distribution_elementwise" in name:
+        return "torch::normal_ (synthetic data generation)"
+    name = name.replace("void ", "").replace("expann::", "")
+    return name[:90]
+
+
+def stats(path, out):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+    return rows
+
+
+def trace_durations(path):
+    """per-kernel list of (duration_ns, grid) from the kernel trace"""
+    d = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        grid = int(r.get("Grid_Size") or r.get("Grid_Size_X"))
+        d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                           grid))
+    return d
+
+
+def counters(path):
+    d = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[(short(r["Kernel_Name"]), r["Counter_Name"])].append(
+            (float(r["Counter_Value"]), int(r["Grid_Size"])))
+    return d
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    outdir = os.path.join(ROOT, "profiles")
+    summary = {"tag": tag, "runs": {}}
+
+    def one(pattern):
+        g = glob.glob(os.path.join(src, pattern))
+        return g[0] if g else None
+
+    for run in ("c2", "m1"):
+        st = one(f"{run}_trace/*/*_kernel_stats.csv")
+        tr = one(f"{run}_trace/*/*_kernel_trace.csv")
+        if not st:
+            continue
+        stats(st, os.path.join(outdir, f"{tag}_kernel_stats_{run}.csv"))
+        dur = trace_durations(tr)
+        entry = {}
+        for k, v in dur.items():
+            if "torch" in k or "rocclr" in k:
+                continue
+            # the full-base launches (last threshold level) are the long ones: the sample
+            # levels scan 1/32 and 1/1024 of the rows with the same grid
+            tmax = max(t for t, _ in v)
+            gmax = max(g for _, g in v)
+            full = [t for t, g in v if t >= 0.5 * tmax]
+            entry[k] = {"launches_full_grid": len(full), "grid_threads": gmax,
+                        "avg_ms_full_grid": sum(full) / len(full) / 1e6,
+                        "launches_all": len(v), "total_ms_all": sum(t for t, _ in v) / 1e6}
+        summary["runs"][run] = {"kernels": entry}
+        for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            c = one(f"{run}_{sub}/*/*_counter_collection.csv")
+            if not c:
+                continue
+            for (k, name), vals in counters(c).items():
+                if k not in entry:
+                    continue
+                vmax = max(x for x, _ in vals)
+                full = [x for x, g in vals if x >= 0.5 * vmax]
+                entry[k][f"{name}_KiB_avg_full_grid"] = sum(full) / len(full)
+    # calibration of FETCH_SIZE on the single-pass run
+    cal = None
+    m1 = summary["runs"].get("m1", {}).get("kernels", {})
+    for k, e in m1.items():
+        if k.startswith("scan_filter") and "FETCH_SIZE_KiB_avg_full_grid" in e:
+            known = 1_000_000 * 128 * 4
+            cal = known / (e["FETCH_SIZE_KiB_avg_full_grid"] * 1024)
+            e["known_bytes_per_launch"] = known
+    summary["fetch_size_calibration"] = {
+        "factor": cal, "basis": "m=1 scan: one pass over N*d*4 = 512e6 B, base > Infinity Cache",
+        "guide": "MI355X_MICROARCH.md HBM: FETCH_SIZE = half of streamed bytes on gfx950"}
+    for run, r in summary["runs"].items():
+        for k, e in r["kernels"].items():
+            f = e.get("FETCH_SIZE_KiB_avg_full_grid")
+            w = e.get("WRITE_SIZE_KiB_avg_full_grid")
+            if f is not None and cal:
+                e["hbm_read_bytes_per_launch"] = f * 1024 * cal
+            if w is not None:
+                e["hbm_write_bytes_per_launch"] = w * 1024
+            if f is not None and cal:
+                e["hbm_traffic_bytes_per_launch"] = f * 1024 * cal + (w or 0) * 1024
+    with open(os.path.join(outdir, f"{tag}_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True)[:3500])
+
+
+if __name__ == "__main__":
+    main()
