@@ -94,6 +94,30 @@ def cpu_baseline(base_host, queries_host, k, budget_s):
             "single_thread_value": round(qps1, 2)}
 
 
+def profiled_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_summary.json, made by profiles/run_rocprof.sh + summarize.py on the same
+    default command).  PMC counters cannot be read from inside the timed process, so this is
+    the per-launch figure of that profile run; None when no profile matches the kernel."""
+    import glob
+    import re
+    m = re.match(r"(\w+)<(\d+),(\d+),(L2|IP)>", kernel_name or "")
+    if not m:
+        return None, None
+    want = (m.group(1), int(m.group(2)), int(m.group(3)), m.group(4) == "IP")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            summ = json.load(open(path))
+        except Exception:
+            continue
+        for k, e in summ.get("runs", {}).get("c2", {}).get("kernels", {}).items():
+            mm = re.match(r"(\w+?)_kernel<(\d+), (\d+), (true|false)>", k)
+            if mm and (mm.group(1), int(mm.group(2)), int(mm.group(3)), mm.group(4) == "true") == want \
+                    and "hbm_traffic_bytes_per_launch" in e:
+                return e["hbm_traffic_bytes_per_launch"], os.path.basename(path)
+    return None, None
+
+
 def main():
     a = parse()
     import torch
@@ -111,8 +135,8 @@ def main():
     from expann_amd import GpuBruteForceEngine, merge_topk_device
 
     # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
-    lo = rank * a.n // G
-    hi = (rank + 1) * a.n // G
+    from expann_amd.sharded import shard_range
+    lo, hi = shard_range(a.n, rank, G)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
@@ -125,20 +149,32 @@ def main():
         eng.set_option("query_tile", a.query_tile)
     ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
     dists = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
-    if G > 1:
-        all_ids = torch.empty(G, a.m, a.k, dtype=torch.int64, device=dev)
-        all_d = torch.empty(G, a.m, a.k, dtype=torch.float32, device=dev)
-        out_ids = torch.empty_like(ids)
-        out_d = torch.empty_like(dists)
+    out_ids = torch.empty_like(ids)
+    out_d = torch.empty_like(dists)
+    gather_bufs = {}
     stream = torch.cuda.current_stream().cuda_stream
 
+    def local_search(q, k):
+        eng.search_device(q.data_ptr(), q.shape[0], k, ids.data_ptr(), dists.data_ptr(), stream)
+        return ids, dists
+
+    def merge(all_ids, all_d):
+        merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), G, a.m, a.k,
+                          out_ids.data_ptr(), out_d.data_ptr(), stream)
+        return out_ids, out_d
+
+    def alloc_gather(t):
+        key = t.dtype
+        if key not in gather_bufs:
+            gather_bufs[key] = torch.empty((G * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                                           device=dev)
+        return gather_bufs[key]
+
+    from expann_amd.sharded import ShardedSearch
+    ss = ShardedSearch(dist if G > 1 else None, G, local_search, merge, alloc_gather)
+
     def step():
-        eng.search_device(queries.data_ptr(), a.m, a.k, ids.data_ptr(), dists.data_ptr(), stream)
-        if G > 1:
-            dist.all_gather_into_tensor(all_ids, ids)
-            dist.all_gather_into_tensor(all_d, dists)
-            merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), G, a.m, a.k,
-                              out_ids.data_ptr(), out_d.data_ptr(), stream)
+        ss.search(queries, a.k)
 
     for _ in range(a.warmup):
         step()
@@ -169,8 +205,13 @@ def main():
         passes = prof["scan_query_tiles"] / launches
         alg_bytes = passes * n_local * a.d * 4          # one pass of a query tile = N*d*4 B
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        default_cfg = (a.n, a.d, a.m, a.k, G) == (1_000_000, 128, 10_000, 10, 1)
+        traffic, traffic_src = profiled_traffic(prof["scan_kernel"]) if default_cfg else (None, None)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": round(traffic / 1e9, 2) if traffic else None,
+                    "traffic_unit": "GB per launch (rocprofv3 PMC, FETCH_SIZE x2 calibrated + "
+                                    "WRITE_SIZE)", "traffic_source": traffic_src,
                     "kernel": prof["scan_kernel"], "kernel_ms": round(scan_ms, 4),
                     "launches": int(launches), "query_tile": int(prof["query_tile"]),
                     "passes_per_launch": passes,

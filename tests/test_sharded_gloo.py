@@ -1,0 +1,96 @@
+"""world_size-2 (and 3) test of the multi-GPU orchestration over gloo on CPU: shard ranges, id
+offsets, all-gather layout and merge order.  The local search and the merge are CPU stand-ins
+built on the oracle (the production ones are HIP kernels, covered by
+tests/test_gpu_full_size.py::test_c2_shard_and_merge_equals_unsharded)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _merge_np(all_ids, all_d):
+    """numpy statement of merge_topk_kernel: per query the k smallest (score, id) of G lists."""
+    G, m, k = all_ids.shape
+    out_i = np.empty((m, k), np.int64)
+    out_d = np.empty((m, k), np.float32)
+    for q in range(m):
+        ids = all_ids[:, q, :].reshape(-1).astype(np.uint64)
+        d = all_d[:, q, :].reshape(-1)
+        order = np.lexsort((ids, d))[:k]
+        out_i[q] = ids[order].astype(np.int64)
+        out_d[q] = d[order]
+    return out_i, out_d
+
+
+def _worker(rank, world, port, n, d, m, k, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import oracle_ctypes as oc
+    from expann_amd.sharded import ShardedSearch, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(77)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base[n // 3] = base[2 * n // 3]          # a cross-shard exact tie
+    queries = rng.standard_normal((m, d)).astype(np.float32)
+    queries[0] = base[n // 3]
+    lo, hi = shard_range(n, rank, world)
+
+    def local_search(q, kk):
+        ids, dd = oc.brute_force(base[lo:hi], q.numpy(), kk)
+        ids = np.where(ids == np.uint64(2 ** 64 - 1), ids, ids + np.uint64(lo))
+        return torch.from_numpy(ids.view(np.int64)), torch.from_numpy(dd)
+
+    def merge(all_ids, all_d):
+        i, dd = _merge_np(all_ids.numpy(), all_d.numpy())
+        return torch.from_numpy(i), torch.from_numpy(dd)
+
+    ss = ShardedSearch(dist, world, local_search, merge,
+                       lambda t: torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype))
+    ids, dd = ss.search(torch.from_numpy(queries), k)
+    ref_ids, ref_d = oc.brute_force(base, queries, k)
+    ok = np.array_equal(ids.numpy().view(np.uint64), ref_ids) and np.array_equal(dd.numpy(), ref_d)
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_matches_unsharded(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 3001, 64, 9, 10, out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(out.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_shard_ranges_partition_the_base():
+    from expann_amd.sharded import shard_range
+    for n in (1, 7, 1000, 1_000_000, 10_000_019):
+        for world in (1, 2, 3, 4, 8):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
