@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "scan_f32.hpp"
+#include "scan_gemm_f32.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
 
@@ -55,12 +56,15 @@ struct expann_index {
 	uint32_t* d_overflow = nullptr;  // [4]: overflow count
 	unsigned long long* d_total = nullptr;
 	uint32_t* h_flags = nullptr;     // pinned [4]
+	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
+	float* d_theta = nullptr;        // [m_alloc]
 	void* d_q = nullptr;             // host-API staging
 	uint64_t* d_ids = nullptr;
 	float* d_dists = nullptr;
 	size_t io_q_bytes = 0, io_out = 0;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
+	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter_f32), 2 GEMM form (MFMA)
 	// profiling
 	bool profiling = false;
 	hipEvent_t ev[kEventPairs][2];
@@ -192,8 +196,11 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		if (h->d_cnt) hipFree(h->d_cnt);
 		if (h->d_tau[0]) hipFree(h->d_tau[0]);
 		if (h->d_tau[1]) hipFree(h->d_tau[1]);
+		if (h->d_theta) hipFree(h->d_theta);
 		h->d_cnt = nullptr;
+		h->d_theta = nullptr;
 		h->d_tau[0] = h->d_tau[1] = nullptr;
+		HIP_TRY(h, hipMalloc(&h->d_theta, sizeof(float) * m));
 		HIP_TRY(h, hipMalloc(&h->d_cnt, sizeof(uint32_t) * m));
 		HIP_TRY(h, hipMalloc(&h->d_tau[0], sizeof(float) * m));
 		HIP_TRY(h, hipMalloc(&h->d_tau[1], sizeof(float) * m));
@@ -215,6 +222,43 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 	return EXPANN_OK;
 }
 
+// ---- GEMM-form (MFMA) scan: dims it is built for ----------------------------------------
+using GemmFn = void (*)(GemmScanParams);
+using NormFn = void (*)(const float*, uint32_t, float, float*);
+using ThetaFn = void (*)(const float*, uint32_t, const float*, float, float*);
+struct GemmVariant {
+	int d;
+	GemmFn scan;
+	NormFn norms;
+	ThetaFn theta;
+	const char* name;
+};
+const GemmVariant kGemmF32[] = {
+    {64, scan_gemm_f32_kernel<64>, row_norms_kernel<64>, query_theta_kernel<64>, "scan_gemm_f32<64>"},
+    {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
+
+const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
+	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
+		return nullptr;
+	if (h->opt_scan_kernel == 0 && (m < 96 || h->n < 4096))
+		return nullptr;  // small batches are HBM-bound: the direct scan wins
+	for (const auto& v : kGemmF32)
+		if (v.d == h->dim)
+			return &v;
+	return nullptr;
+}
+
+int ensure_bnorm(expann_index* h, const GemmVariant* gv, hipStream_t st) {
+	if (h->d_bnorm)
+		return EXPANN_OK;
+	HIP_TRY(h, hipMalloc(&h->d_bnorm, sizeof(float) * h->n));
+	const uint32_t blocks = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
+	hipLaunchKernelGGL(gv->norms, dim3(blocks), dim3(kBlock), 0, st, (const float*)h->d_base,
+	                   (uint32_t)h->n, 1.0f - gemm_filter_eps(h->dim), h->d_bnorm);
+	HIP_TRY(h, hipGetLastError());
+	return EXPANN_OK;
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
@@ -232,6 +276,14 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "k too large for the candidate buffers (k <= " +
 		                                           std::to_string(kMaxCap / 2) + ")");
 	const int cus = num_cus(h->device);
+	const GemmVariant* gv = pick_gemm(h, m);
+	if (h->opt_scan_kernel == 2 && !gv)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "GEMM-form scan: f32 L2 with dim 64 or 128 only");
+	if (gv) {
+		int rc = ensure_bnorm(h, gv, st);
+		if (rc != EXPANN_OK)
+			return rc;
+	}
 
 	for (int attempt = 0;; ++attempt) {
 		int rc = ensure_workspace(h, m, cap);
@@ -264,10 +316,49 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
 			if (!first)
 				HIP_TRY(h, hipMemsetAsync(h->d_cnt, 0, sizeof(uint32_t) * m, st));
+			const bool use_gemm = gv && !first;
 			const bool timed = last && h->profiling && h->ev_used < kEventPairs;
-			if (timed)
-				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-			hipLaunchKernelGGL(sv->fn, dim3(n_chunks * n_qtiles), dim3(kBlock), 0, st, sp);
+			uint32_t passes = n_qtiles;
+			const char* kname = sv->name;
+			uint32_t qt_used = (uint32_t)sv->tq;
+			if (use_gemm) {
+				// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
+				hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+				                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
+				                   (const float*)sp.tau, 1.0f - gemm_filter_eps(h->dim), h->d_theta);
+				GemmScanParams gp{};
+				gp.base = (const float*)h->d_base;
+				gp.bnorm = h->d_bnorm;
+				gp.n_rows = (uint32_t)h->n;
+				const uint32_t n_tiles = (uint32_t)((h->n + kGemmTB - 1) / kGemmTB);
+				gp.n_tiles_sel = last ? n_tiles
+				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
+				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
+				gp.n_qtiles = (uint32_t)((m + kGemmTQ - 1) / kGemmTQ);
+				gp.queries = (const float*)d_queries;
+				gp.theta = h->d_theta;
+				gp.m = (uint32_t)m;
+				gp.cand_cnt = h->d_cnt;
+				gp.cand = h->d_cand;
+				gp.cap = cap;
+				// ~64 tile steps per workgroup, but at least ~4 workgroups per CU in total
+				uint32_t gchunks = std::max<uint32_t>(1, gp.n_tiles_sel / 64);
+				const uint32_t want = (uint32_t)((4L * cus + gp.n_qtiles - 1) / gp.n_qtiles);
+				gchunks = std::max(gchunks, std::min(want, std::max<uint32_t>(1, gp.n_tiles_sel / 8)));
+				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
+				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
+				if (timed)
+					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+				hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kBlock),
+				                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
+				passes = gp.n_qtiles;
+				kname = gv->name;
+				qt_used = kGemmTQ;
+			} else {
+				if (timed)
+					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+				hipLaunchKernelGGL(sv->fn, dim3(n_chunks * n_qtiles), dim3(kBlock), 0, st, sp);
+			}
 			if (timed) {
 				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 				h->ev_used++;
@@ -275,10 +366,10 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			if (last && (timed || !h->profiling)) {
 				h->prof.scan_launches++;
 				h->prof.scan_rows += h->n;
-				h->prof.scan_query_tiles += n_qtiles;
-				h->prof.query_tile = (uint32_t)sv->tq;
+				h->prof.scan_query_tiles += passes;
+				h->prof.query_tile = qt_used;
 				h->prof.levels = (uint32_t)levels.size();
-				std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", sv->name);
+				std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", kname);
 			}
 			HIP_TRY(h, hipGetLastError());
 
@@ -293,6 +384,10 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			sel.out_dists = last ? d_dists : nullptr;
 			sel.tau_out = last ? nullptr : h->d_tau[li & 1];
 			sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
+			sel.rerank_base = use_gemm ? (const float*)h->d_base : nullptr;
+			sel.rerank_queries = (const float*)d_queries;
+			sel.dim = (uint32_t)h->dim;
+			sel.metric_ip = ip ? 1u : 0u;
 			sel.overflow = h->d_overflow;
 			sel.total_cand = last ? h->d_total : nullptr;
 			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
@@ -387,6 +482,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		delete h;
 		return EXPANN_ERR_HIP;
 	}
+	for (const auto& v : kGemmF32)
+		if (v.d == dim)
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        2 * kGemmTB * dim * (int)sizeof(float)) != hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_f32_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
 	*out = h;
 	return EXPANN_OK;
 }
@@ -402,6 +506,8 @@ void expann_destroy(expann_index* h) {
 	if (h->d_tau[0]) hipFree(h->d_tau[0]);
 	if (h->d_tau[1]) hipFree(h->d_tau[1]);
 	if (h->d_overflow) hipFree(h->d_overflow);
+	if (h->d_bnorm) hipFree(h->d_bnorm);
+	if (h->d_theta) hipFree(h->d_theta);
 	if (h->d_total) hipFree(h->d_total);
 	if (h->h_flags) hipHostFree(h->h_flags);
 	if (h->d_q) hipFree(h->d_q);
@@ -461,6 +567,10 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
 	if (h->owns_base && h->d_base)
 		hipFree(h->d_base);
+	if (h->d_bnorm) {
+		hipFree(h->d_bnorm);
+		h->d_bnorm = nullptr;
+	}
 	h->d_base = const_cast<void*>(d_rows);
 	h->owns_base = false;
 	h->n = n;
@@ -656,6 +766,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_query_tile = value;
 	else if (!std::strcmp(name, "cand_capacity"))
 		h->opt_cand_capacity = value;
+	else if (!std::strcmp(name, "scan_kernel"))
+		h->opt_scan_kernel = value;
 	else if (!std::strcmp(name, "sample_ratio"))
 		h->opt_sample_ratio = value < 2 ? 2 : value;
 	else

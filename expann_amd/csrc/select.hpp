@@ -18,6 +18,12 @@ struct SelectParams {
 	float* out_dists;         // [m][k] or nullptr
 	float* tau_out;           // [m] k-th smallest score, or nullptr
 	const float* tau_prev;    // [m] carried forward when fewer than k keys (nullptr: +inf)
+	// re-rank (GEMM-form scan): when rerank_base != nullptr the keys hold only a row number
+	// (low 32 bits); the exact reference-order score is recomputed here before the sort
+	const float* rerank_base;     // [n][dim]
+	const float* rerank_queries;  // [m][dim]
+	uint32_t dim;
+	uint32_t metric_ip;
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
 	unsigned long long* total_cand;  // [1] sum of counts (statistics) or nullptr
 };
@@ -40,8 +46,36 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	while (n2 < c)
 		n2 <<= 1;
 	const uint64_t* src = p.cand + (size_t)qi * p.cap;
-	for (uint32_t i = tid; i < n2; i += kBlock)
-		keys[i] = i < c ? src[i] : kSentinelKey;
+	if (p.rerank_base) {
+		// 16 lanes per candidate row, lane l owns dims l, l+16, ... in increasing order and
+		// the partial sums meet in the _mm512_reduce_add_ps tree: the scores written here are
+		// bit-identical to scan_filter_f32_kernel's (src/distance.h:136-147 / :181-190).
+		const uint32_t l = tid & 15, grp = tid >> 4;  // 16 candidates per pass
+		const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
+		for (uint32_t i0 = 0; i0 < n2; i0 += kBlock / 16) {
+			const uint32_t i = i0 + grp;
+			uint64_t key = kSentinelKey;
+			if (i < c)
+				key = src[i];
+			const uint32_t row = (i < c) ? key_idx(key) : 0u;
+			const float* r = p.rerank_base + (size_t)row * p.dim + l;
+			float acc = 0.0f;
+			for (uint32_t t = 0; t < p.dim / 16; ++t) {
+				if (p.metric_ip) {
+					acc = __builtin_fmaf(q[16 * t], r[16 * t], acc);
+				} else {
+					const float diff = q[16 * t] - r[16 * t];
+					acc = __builtin_fmaf(diff, diff, acc);
+				}
+			}
+			acc = reduce16_ref_order(acc);
+			if (l == 0 && i < n2)
+				keys[i] = (i < c) ? make_key(p.metric_ip ? -acc : acc, row) : kSentinelKey;
+		}
+	} else {
+		for (uint32_t i = tid; i < n2; i += kBlock)
+			keys[i] = i < c ? src[i] : kSentinelKey;
+	}
 	__syncthreads();
 	for (uint32_t size = 2; size <= n2; size <<= 1) {
 		for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {

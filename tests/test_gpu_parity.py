@@ -103,6 +103,44 @@ def test_every_query_tile_gives_the_same_answer(gpu, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,m,k", [
+    (20000, 128, 130, 10),
+    (5000, 64, 200, 10),
+    (4099, 128, 100, 17),     # ragged last tile
+    (1000, 128, 97, 1),
+    (70000, 128, 300, 100),
+    (300, 128, 129, 10),      # fewer rows than one 128-row tile pair
+])
+def test_gemm_form_scan_bit_exact_vs_oracle(gpu, oracle, n, d, m, k):
+    """scan_kernel=2 forces the MFMA GEMM-form candidate filter (+ exact re-rank in the select
+    kernel): the final ids and distances must still be bit-identical to the oracle."""
+    rng = np.random.RandomState(n * 7 + m)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((m, d)).astype(np.float32)
+    eng = _engine(base)
+    eng.set_option("scan_kernel", 2)
+    eng.set_profiling(True)
+    _check(oracle, base, queries, k, eng=eng)
+    prof = eng.get_profile()
+    if n > 1024:
+        assert prof["scan_kernel"].startswith("scan_gemm_f32")
+    eng.close()
+
+
+def test_gemm_form_scan_near_duplicates_and_ties(gpu, oracle):
+    """The expanded form ||b||^2 - 2q.b + ||q||^2 cancels catastrophically for near-duplicate
+    vectors (SURVEY 7 'hard parts'); the slack + exact re-rank must keep the result exact."""
+    rng = np.random.RandomState(42)
+    uniq = (rng.standard_normal((3000, 128)) * 10).astype(np.float32)
+    near = uniq + (rng.standard_normal(uniq.shape) * 1e-4).astype(np.float32)
+    base = np.concatenate([uniq, near, uniq[:500]], 0)
+    queries = np.concatenate([uniq[:100] + np.float32(1e-5), uniq[100:140]], 0)
+    eng = _engine(base)
+    eng.set_option("scan_kernel", 2)
+    _check(oracle, base, queries, 10, eng=eng)
+    eng.close()
+
+
 def test_query_k_single_and_idempotent(gpu, oracle):
     rng = np.random.RandomState(3)
     base = rng.standard_normal((12345, 128)).astype(np.float32)
