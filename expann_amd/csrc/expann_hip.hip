@@ -349,7 +349,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kBlock),
+				hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
 				                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
 				passes = gp.n_qtiles;
 				kname = gv->name;

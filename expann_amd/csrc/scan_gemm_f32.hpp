@@ -88,8 +88,10 @@ __global__ __launch_bounds__(kBlock) void query_theta_kernel(const float* querie
 		theta[qi] = tau[qi] - acc * scale;
 }
 
+constexpr int kGemmThreads = 512;  // 8 waves: 4 query sub-tiles x 2 row halves, 2 waves per SIMD
+
 template <int D>
-__global__ __launch_bounds__(kBlock, 1) void scan_gemm_f32_kernel(GemmScanParams p) {
+__global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f32_kernel(GemmScanParams p) {
 	static_assert(D % 64 == 0 && D <= 128, "built for d = 64, 128");
 	constexpr int CH = D / 4;   // 16-byte chunks per row
 	constexpr int KH = D / 2;   // dims per lane half
@@ -99,39 +101,38 @@ __global__ __launch_bounds__(kBlock, 1) void scan_gemm_f32_kernel(GemmScanParams
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	// wave tile = 32 queries x 64 base rows (1 x 2 MFMA tiles of 32x32).  Two waves share a
+	// SIMD, so one wave's LDS waits / epilogue VALU overlap the other's MFMAs.
 	const int wr = wave >> 1, wc = wave & 1;
 	const int h = lane >> 5, r31 = lane & 31;
 	const uint32_t qtile = blockIdx.x % p.n_qtiles;
 	const uint32_t chunk = blockIdx.x / p.n_qtiles;
 	const uint32_t q0 = qtile * kGemmTQ;
 
-	// ---- query fragments: A[i = r31][k = h*KH + s], two 32-row tiles per wave ------------
-	float a[2][KH];
-#pragma unroll
-	for (int tr = 0; tr < 2; ++tr) {
-		uint32_t qi = q0 + wr * 64 + tr * 32 + r31;
+	// ---- query fragments: A[i = r31][k = h*KH + s] --------------------------------------
+	float a[KH];
+	{
+		uint32_t qi = q0 + wr * 32 + r31;
 		if (qi >= p.m)
 			qi = p.m - 1;
 		const f32x4* src = reinterpret_cast<const f32x4*>(p.queries + (size_t)qi * D + h * KH);
 #pragma unroll
 		for (int g = 0; g < KH / 4; ++g) {
 			const f32x4 v = src[g];
-			a[tr][4 * g + 0] = v[0];
-			a[tr][4 * g + 1] = v[1];
-			a[tr][4 * g + 2] = v[2];
-			a[tr][4 * g + 3] = v[3];
+			a[4 * g + 0] = v[0];
+			a[4 * g + 1] = v[1];
+			a[4 * g + 2] = v[2];
+			a[4 * g + 3] = v[3];
 		}
 	}
-	// thresholds of the 2 x 16 query rows this lane's accumulators belong to
+	// thresholds of the 16 query rows this lane's accumulators belong to
 	// (C/D layout of the 32x32 MFMA: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31)
-	float th[2][16];
+	float th[16];
 #pragma unroll
-	for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-		for (int reg = 0; reg < 16; ++reg) {
-			const uint32_t qi = q0 + wr * 64 + tr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			th[tr][reg] = qi < p.m ? p.theta[qi] : -__builtin_inff();
-		}
+	for (int reg = 0; reg < 16; ++reg) {
+		const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+		th[reg] = qi < p.m ? p.theta[qi] : -__builtin_inff();
+	}
 
 	const uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
@@ -143,15 +144,15 @@ __global__ __launch_bounds__(kBlock, 1) void scan_gemm_f32_kernel(GemmScanParams
 	auto stage = [&](uint32_t t, int buf) {
 		const uint32_t row0 = t * p.tile_stride * kGemmTB;
 #pragma unroll
-		for (int i = 0; i < kGemmTB * CH / kBlock; ++i) {
-			const int S = i * kBlock + tid;
+		for (int i = 0; i < kGemmTB * CH / kGemmThreads; ++i) {
+			const int S = i * kGemmThreads + tid;
 			const int r = S / CH, pc = S % CH;
 			const int c = pc ^ (r & 15);
 			uint32_t grow = row0 + r;
 			if (grow >= p.n_rows)
 				grow = p.n_rows - 1;
 			const float* src = p.base + (size_t)grow * D + c * 4;
-			unsigned char* dst = smem + buf * TILE_BYTES + (i * kBlock + wave * 64) * 16;
+			unsigned char* dst = smem + buf * TILE_BYTES + (i * kGemmThreads + wave * 64) * 16;
 			__builtin_amdgcn_global_load_lds(
 			    (const __attribute__((address_space(1))) void*)src,
 			    (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -167,31 +168,37 @@ __global__ __launch_bounds__(kBlock, 1) void scan_gemm_f32_kernel(GemmScanParams
 		if (t + 1 < t1)
 			stage(t + 1, buf ^ 1);
 
-		f32x16 acc[2][2];
+		f32x16 acc0, acc1;
 #pragma unroll
-		for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-			for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-				for (int e = 0; e < 16; ++e)
-					acc[tr][tc][e] = 0.0f;
+		for (int e = 0; e < 16; ++e) {
+			acc0[e] = 0.0f;
+			acc1[e] = 0.0f;
+		}
 
 		const unsigned char* bt = smem + buf * TILE_BYTES;
 		const int rb0 = wc * 64 + r31, rb1 = rb0 + 32;
 		const int sw = r31 & 15;
+		auto frag = [&](int rb, int g) -> f32x4 {
+			const int c = (h * (CH / 2) + g) ^ sw;
+			return *reinterpret_cast<const f32x4*>(bt + rb * (D * 4) + c * 16);
+		};
+		// fragment registers are double-buffered: group g+1 is read while group g multiplies
+		f32x4 b0 = frag(rb0, 0), b1 = frag(rb1, 0);
 #pragma unroll
 		for (int g = 0; g < KH / 4; ++g) {
-			const int c = (h * (CH / 2) + g) ^ sw;
-			const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt + rb0 * (D * 4) + c * 16);
-			const f32x4 b1 = *reinterpret_cast<const f32x4*>(bt + rb1 * (D * 4) + c * 16);
+			f32x4 nb0 = b0, nb1 = b1;
+			if (g + 1 < KH / 4) {
+				nb0 = frag(rb0, g + 1);
+				nb1 = frag(rb1, g + 1);
+			}
 #pragma unroll
 			for (int kk = 0; kk < 4; ++kk) {
 				const int s = 4 * g + kk;
-				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], b0[kk], acc[0][0], 0, 0, 0);
-				acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], b1[kk], acc[0][1], 0, 0, 0);
-				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s], b0[kk], acc[1][0], 0, 0, 0);
-				acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s], b1[kk], acc[1][1], 0, 0, 0);
+				acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[kk], acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[kk], acc1, 0, 0, 0);
 			}
+			b0 = nb0;
+			b1 = nb1;
 		}
 
 		// ---- epilogue: threshold test, rare candidate append ---------------------------
@@ -200,19 +207,25 @@ __global__ __launch_bounds__(kBlock, 1) void scan_gemm_f32_kernel(GemmScanParams
 		for (int tc = 0; tc < 2; ++tc) {
 			const uint32_t brow = row0 + wc * 64 + tc * 32 + r31;
 			const float bn = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
+			const f32x16& acc = tc ? acc1 : acc0;
 #pragma unroll
-			for (int tr = 0; tr < 2; ++tr) {
+			for (int r4 = 0; r4 < 16; r4 += 4) {
+				float tv[4];
+				bool any = false;
 #pragma unroll
-				for (int reg = 0; reg < 16; ++reg) {
-					const float tv = __builtin_fmaf(-2.0f, acc[tr][tc][reg], bn);
-					const bool pass = tv <= th[tr][reg];
-					if (__builtin_amdgcn_ballot_w64(pass) != 0) {
-						if (pass) {
-							const uint32_t qi =
-							    q0 + wr * 64 + tr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+				for (int e = 0; e < 4; ++e) {
+					tv[e] = __builtin_fmaf(-2.0f, acc[r4 + e], bn);
+					any |= tv[e] <= th[r4 + e];
+				}
+				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const int reg = r4 + e;
+						if (tv[e] <= th[reg]) {
+							const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 							const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
 							if (slot < p.cap)
-								p.cand[(size_t)qi * p.cap + slot] = make_key(tv, brow);
+								p.cand[(size_t)qi * p.cap + slot] = make_key(tv[e], brow);
 						}
 					}
 				}
