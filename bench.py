@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (155 measured)
 
 
 def parse():
@@ -101,19 +102,27 @@ def profiled_traffic(kernel_name):
     the per-launch figure of that profile run; None when no profile matches the kernel."""
     import glob
     import re
-    m = re.match(r"(\w+)<(\d+),(\d+),(L2|IP)>", kernel_name or "")
-    if not m:
+
+    def norm(name):
+        mm = re.match(r"(?:void )?(?:expann::)?(\w+?)(?:_kernel)?<([^>]*)>", name or "")
+        if not mm:
+            return None
+        args = []
+        for x in mm.group(2).split(","):
+            x = x.strip()
+            args.append({"L2": 0, "false": 0, "IP": 1, "true": 1}.get(x, x))
+        return (mm.group(1), tuple(str(x) for x in args))
+
+    want = norm(kernel_name)
+    if not want:
         return None, None
-    want = (m.group(1), int(m.group(2)), int(m.group(3)), m.group(4) == "IP")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
         try:
             summ = json.load(open(path))
         except Exception:
             continue
         for k, e in summ.get("runs", {}).get("c2", {}).get("kernels", {}).items():
-            mm = re.match(r"(\w+?)_kernel<(\d+), (\d+), (true|false)>", k)
-            if mm and (mm.group(1), int(mm.group(2)), int(mm.group(3)), mm.group(4) == "true") == want \
-                    and "hbm_traffic_bytes_per_launch" in e:
+            if norm(k) == want and "hbm_traffic_bytes_per_launch" in e:
                 return e["hbm_traffic_bytes_per_launch"], os.path.basename(path)
     return None, None
 
@@ -207,19 +216,26 @@ def main():
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         default_cfg = (a.n, a.d, a.m, a.k, G) == (1_000_000, 128, 10_000, 10, 1)
         traffic, traffic_src = profiled_traffic(prof["scan_kernel"]) if default_cfg else (None, None)
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": round(traffic / 1e9, 2) if traffic else None,
-                    "traffic_unit": "GB per launch (rocprofv3 PMC, FETCH_SIZE x2 calibrated + "
-                                    "WRITE_SIZE)", "traffic_source": traffic_src,
-                    "kernel": prof["scan_kernel"], "kernel_ms": round(scan_ms, 4),
-                    "launches": int(launches), "query_tile": int(prof["query_tile"]),
-                    "passes_per_launch": passes,
+        hbm_view = {"achieved_GBps": round(achieved, 1), "frac_of_8TBps": round(achieved / HBM_PEAK_GBS, 4),
+                    "passes_per_launch": passes, "query_tile": int(prof["query_tile"]),
                     "single_pass_equiv_GBps": round(n_local * a.d * 4 / (scan_ms * 1e-3) / 1e9, 2)
-                    if scan_ms > 0 else 0.0,
-                    "flops_direct_TFLOPs": round(3.0 * n_local * a.d * a.m / (scan_ms * 1e-3) / 1e12, 2)
-                    if scan_ms > 0 else 0.0,
-                    "candidates_per_query": round(prof["candidates"] / a.m, 1)}
+                    if scan_ms > 0 else 0.0}
+        if prof["scan_kernel"].startswith("scan_gemm"):
+            # GEMM-form filter on the matrix cores: algorithmic flops = 2*N*d*m
+            flops = 2.0 * n_local * a.d * a.m
+            tf = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+        else:
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+        roofline.update({
+            "traffic": round(traffic / 1e9, 2) if traffic else None,
+            "traffic_unit": "GB per launch (rocprofv3 PMC, FETCH_SIZE x2 calibrated + WRITE_SIZE)",
+            "traffic_source": traffic_src, "kernel": prof["scan_kernel"],
+            "kernel_ms": round(scan_ms, 4), "launches": int(launches),
+            "algorithmic_bytes_per_launch": alg_bytes, "hbm_view": hbm_view,
+            "candidates_per_query": round(prof["candidates"] / a.m, 1)})
         out = {"metric": "queries/sec at recall@10=1.0 (exact brute force), 1Mxd128 fp32, k=10",
                "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

@@ -341,10 +341,24 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				gp.cand_cnt = h->d_cnt;
 				gp.cand = h->d_cand;
 				gp.cap = cap;
-				// ~64 tile steps per workgroup, but at least ~4 workgroups per CU in total
-				uint32_t gchunks = std::max<uint32_t>(1, gp.n_tiles_sel / 64);
-				const uint32_t want = (uint32_t)((4L * cus + gp.n_qtiles - 1) / gp.n_qtiles);
-				gchunks = std::max(gchunks, std::min(want, std::max<uint32_t>(1, gp.n_tiles_sel / 8)));
+				// One workgroup per CU is resident (128 KiB of LDS), so the launch runs in rounds
+				// of `cus` workgroups: pick the row-chunk count that minimises
+				// rounds x (steps per workgroup + ~2 steps of prologue).
+				uint32_t gchunks = 1;
+				{
+					const uint32_t gmax = std::max<uint32_t>(1, gp.n_tiles_sel / 4);
+					double best = 1e300;
+					for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 1024); ++g) {
+						const uint32_t steps = (gp.n_tiles_sel + g - 1) / g;
+						const uint64_t blocks = (uint64_t)g * gp.n_qtiles;
+						const uint64_t rounds = (blocks + cus - 1) / cus;
+						const double cost = (double)rounds * (steps + 2.0);
+						if (cost < best * 0.999) {
+							best = cost;
+							gchunks = g;
+						}
+					}
+				}
 				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)

@@ -17,9 +17,10 @@
 // with global_load_lds_dwordx4 (two LDS buffers; the next tile streams in while the MFMAs of
 // the current one run), XOR-swizzled through the SOURCE address so that the 16-byte fragment
 // reads (ds_read_b128, rows 512 B apart) are bank-conflict free.  The query tile's fragments
-// (2 x d/2 VGPRs per lane) are loaded once per workgroup.  4 waves = 2x2 sub-tiles of 64x64,
-// each 2x2 MFMA tiles of 32x32; a lane's k-slice is dims [0,d/2) for lanes 0-31 and [d/2,d)
-// for lanes 32-63 (any k order is a valid dot product; the slack covers the rounding).
+// (d/2 VGPRs per lane) are loaded once per workgroup.  8 waves = 4 x 2 sub-tiles of 32 queries
+// x 64 rows (1 x 2 MFMA tiles of 32x32), two waves per SIMD; a lane's k-slice is dims [0,d/2)
+// for lanes 0-31 and [d/2,d) for lanes 32-63 (any k order is a valid dot product; the slack
+// covers the rounding).
 #pragma once
 #include "common.hpp"
 
@@ -163,12 +164,53 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f32_kernel(GemmScan
 		stage(t0, 0);
 	__syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier)
 
+	// ---- epilogue: threshold test on one 32x64 accumulator pair, rare candidate append ----
+	auto epilogue = [&](const f32x16& acc0, const f32x16& acc1, uint32_t row0) {
+#pragma unroll
+		for (int tc = 0; tc < 2; ++tc) {
+			const uint32_t brow = row0 + wc * 64 + tc * 32 + r31;
+			const float bn = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
+			const f32x16& acc = tc ? acc1 : acc0;
+#pragma unroll
+			for (int r4 = 0; r4 < 16; r4 += 4) {
+				float tv[4];
+				bool any = false;
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					tv[e] = __builtin_fmaf(-2.0f, acc[r4 + e], bn);
+					any |= tv[e] <= th[r4 + e];
+				}
+				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const int reg = r4 + e;
+						if (tv[e] <= th[reg]) {
+							const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+							const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
+							if (slot < p.cap)
+								p.cand[(size_t)qi * p.cap + slot] = make_key(tv[e], brow);
+						}
+					}
+				}
+			}
+		}
+	};
+
+	// The two waves of a SIMD (w and w+4) would otherwise run their MFMA phases and their
+	// VALU epilogues in lockstep and leave the matrix pipe idle during the epilogues; waves
+	// 4-7 defer the epilogue of tile t to the start of step t+1, under the partner's MFMAs.
+	const bool deferred = wave >= 4;
+	f32x16 acc0, acc1;
+	uint32_t prev_row0 = 0;
+	bool have_prev = false;
+
 	int buf = 0;
 	for (uint32_t t = t0; t < t1; ++t, buf ^= 1) {
 		if (t + 1 < t1)
 			stage(t + 1, buf ^ 1);
+		if (deferred && have_prev)
+			epilogue(acc0, acc1, prev_row0);
 
-		f32x16 acc0, acc1;
 #pragma unroll
 		for (int e = 0; e < 16; ++e) {
 			acc0[e] = 0.0f;
@@ -201,38 +243,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f32_kernel(GemmScan
 			b1 = nb1;
 		}
 
-		// ---- epilogue: threshold test, rare candidate append ---------------------------
 		const uint32_t row0 = t * p.tile_stride * kGemmTB;
-#pragma unroll
-		for (int tc = 0; tc < 2; ++tc) {
-			const uint32_t brow = row0 + wc * 64 + tc * 32 + r31;
-			const float bn = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
-			const f32x16& acc = tc ? acc1 : acc0;
-#pragma unroll
-			for (int r4 = 0; r4 < 16; r4 += 4) {
-				float tv[4];
-				bool any = false;
-#pragma unroll
-				for (int e = 0; e < 4; ++e) {
-					tv[e] = __builtin_fmaf(-2.0f, acc[r4 + e], bn);
-					any |= tv[e] <= th[r4 + e];
-				}
-				if (__builtin_amdgcn_ballot_w64(any) != 0) {
-#pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						const int reg = r4 + e;
-						if (tv[e] <= th[reg]) {
-							const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-							const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
-							if (slot < p.cap)
-								p.cand[(size_t)qi * p.cap + slot] = make_key(tv[e], brow);
-						}
-					}
-				}
-			}
+		if (!deferred) {
+			epilogue(acc0, acc1, row0);
+		} else {
+			prev_row0 = row0;
+			have_prev = true;
 		}
 		__syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `buf`
 	}
+	if (deferred && have_prev)
+		epilogue(acc0, acc1, prev_row0);
 }
 
 }  // namespace expann
