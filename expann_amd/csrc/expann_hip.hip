@@ -17,6 +17,7 @@
 
 #include "scan_f32.hpp"
 #include "scan_gemm_f32.hpp"
+#include "scan_int8.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
 
@@ -39,7 +40,11 @@ struct Level {
 
 struct expann_index {
 	int dim = 0, dtype = 0, metric = 0, device = 0;
-	size_t elem = 4;
+	size_t elem = 4;    // bytes per stored element
+	size_t q_elem = 4;  // bytes per query element at the ABI (f32 for F32/U8 rows, int8 for I8)
+	int int_mode = -1;  // IntMode for 8-bit rows
+	uint8_t* d_q8 = nullptr;  // U8 rows: queries truncated to uint8
+	size_t q8_bytes = 0;
 	std::vector<unsigned char> staging;  // store_vector() rows until build()
 	size_t n_staged = 0;
 	void* d_base = nullptr;
@@ -142,6 +147,54 @@ struct ScoreVariant {
 const ScoreVariant kScoreF32[] = {SCORE_V(64),  SCORE_V(128), SCORE_V(256), SCORE_V(512),
                                   SCORE_V(768), SCORE_V(832), SCORE_V(960), SCORE_V(1024)};
 #undef SCORE_V
+
+// 8-bit rows
+struct ScanI8Variant {
+	int d, tq, mode;
+	ScanFn fn;
+	const char* name;
+};
+#define SCAN_I8_M(D, TQ, MODE, MN) {D, TQ, MODE, scan_filter_i8_kernel<D, TQ, MODE>, "scan_filter_i8<" #D "," #TQ "," MN ">"}
+#define SCAN_I8(D, TQ) SCAN_I8_M(D, TQ, kU8L2, "U8L2"), SCAN_I8_M(D, TQ, kI8L2, "I8L2"), \
+	SCAN_I8_M(D, TQ, kI8L2Ref, "I8L2REF"), SCAN_I8_M(D, TQ, kI8IP, "I8IP")
+const ScanI8Variant kScanI8[] = {SCAN_I8(64, 1),  SCAN_I8(64, 16), SCAN_I8(128, 1), SCAN_I8(128, 4),
+                                 SCAN_I8(128, 16), SCAN_I8(256, 1), SCAN_I8(256, 8), SCAN_I8(768, 1),
+                                 SCAN_I8(768, 4),  SCAN_I8(768, 8), SCAN_I8(960, 1), SCAN_I8(960, 4)};
+#undef SCAN_I8
+#undef SCAN_I8_M
+
+const ScanI8Variant* pick_scan_i8(int d, int mode, size_t m, long forced_tq) {
+	const ScanI8Variant* best = nullptr;
+	for (const auto& v : kScanI8) {
+		if (v.d != d || v.mode != mode)
+			continue;
+		if (forced_tq > 0) {
+			if (v.tq == forced_tq)
+				return &v;
+			continue;
+		}
+		if (!best) {
+			best = &v;
+			continue;
+		}
+		const bool v_covers = (size_t)v.tq >= m, b_covers = (size_t)best->tq >= m;
+		if (v_covers && (!b_covers || v.tq < best->tq))
+			best = &v;
+		else if (!v_covers && !b_covers && v.tq > best->tq)
+			best = &v;
+	}
+	return best;
+}
+
+using ScoreI8Fn = void (*)(ScoreIdsI8Params);
+struct ScoreI8Variant {
+	int d, mode;
+	ScoreI8Fn fn;
+};
+#define SCORE_I8(D) {D, kU8L2, score_ids_i8_kernel<D, kU8L2>}, {D, kI8L2, score_ids_i8_kernel<D, kI8L2>}, \
+	{D, kI8L2Ref, score_ids_i8_kernel<D, kI8L2Ref>}, {D, kI8IP, score_ids_i8_kernel<D, kI8IP>}
+const ScoreI8Variant kScoreI8[] = {SCORE_I8(64), SCORE_I8(128), SCORE_I8(256), SCORE_I8(768), SCORE_I8(960)};
+#undef SCORE_I8
 
 uint32_t pow2ceil(uint32_t x) {
 	uint32_t p = 1;
@@ -263,11 +316,45 @@ int ensure_bnorm(expann_index* h, const GemmVariant* gv, hipStream_t st) {
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
 	const bool ip = (h->metric == EXPANN_METRIC_IP);
-	const ScanVariant* sv = pick_scan_f32(h->dim, ip, m, h->opt_query_tile);
-	if (!sv)
+	struct {
+		ScanFn fn;
+		int tq;
+		const char* name;
+	} svs{nullptr, 0, ""};
+	if (h->dtype == EXPANN_DTYPE_F32) {
+		const ScanVariant* v = pick_scan_f32(h->dim, ip, m, h->opt_query_tile);
+		if (v)
+			svs = {v->fn, v->tq, v->name};
+	} else {
+		const ScanI8Variant* v = pick_scan_i8(h->dim, h->int_mode, m, h->opt_query_tile);
+		if (v)
+			svs = {v->fn, v->tq, v->name};
+	}
+	if (!svs.fn)
 		return h->fail(EXPANN_ERR_UNSUPPORTED,
-		               "no fp32 scan kernel for dim " + std::to_string(h->dim) +
+		               "no scan kernel for dim " + std::to_string(h->dim) +
 		                   " / query_tile " + std::to_string(h->opt_query_tile));
+	const auto* sv = &svs;
+	if (h->dtype == EXPANN_DTYPE_U8) {
+		// fp32 queries -> uint8 (trunc); values outside [0,255] are counted and rejected below
+		const size_t nv = m * (size_t)h->dim;
+		if (nv > h->q8_bytes) {
+			if (h->d_q8) hipFree(h->d_q8);
+			h->d_q8 = nullptr;
+			h->q8_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_q8, nv));
+			h->q8_bytes = nv;
+		}
+		int rcw = ensure_workspace(h, m, 2048);
+		if (rcw != EXPANN_OK)
+			return rcw;
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow + 1, 0, sizeof(uint32_t), st));
+		hipLaunchKernelGGL(u8_query_prep_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->d_q8,
+		                   h->d_overflow + 1);
+		HIP_TRY(h, hipGetLastError());
+		d_queries = h->d_q8;
+	}
 	uint32_t cap = h->opt_cand_capacity > 0
 	                   ? (uint32_t)h->opt_cand_capacity
 	                   : pow2ceil((uint32_t)std::max<size_t>(2048, 64 * k));
@@ -291,7 +378,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			return rc;
 		const std::vector<Level> levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
 		const uint32_t n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
-		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t) * 4, st));
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
 		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
 		for (size_t li = 0; li < levels.size(); ++li) {
 			const Level& L = levels[li];
@@ -399,7 +486,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			sel.tau_out = last ? nullptr : h->d_tau[li & 1];
 			sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
 			sel.rerank_base = use_gemm ? (const float*)h->d_base : nullptr;
-			sel.rerank_queries = (const float*)d_queries;
+			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
 			sel.dim = (uint32_t)h->dim;
 			sel.metric_ip = ip ? 1u : 0u;
 			sel.overflow = h->d_overflow;
@@ -417,6 +504,11 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		unsigned long long tot;
 		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
 		h->prof.candidates = tot;
+		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
+			return h->fail(EXPANN_ERR_UNSUPPORTED,
+			               std::to_string(h->h_flags[1]) +
+			                   " query values outside [0,255]: the uint8 metric "
+			                   "(dist2_compressed) is only defined for 8-bit valued queries");
 		if (h->h_flags[0] == 0)
 			return EXPANN_OK;
 		// some candidate list overflowed: retry with 4x the capacity
@@ -454,12 +546,35 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		g_create_error = "dim must be a positive multiple of 16 (the reference kernels require it)";
 		return EXPANN_ERR_INVALID_ARG;
 	}
-	if (dtype != EXPANN_DTYPE_F32) {
-		g_create_error = "only EXPANN_DTYPE_F32 is implemented in this build";
-		return EXPANN_ERR_UNSUPPORTED;
+	int int_mode = -1;
+	if (dtype == EXPANN_DTYPE_F32) {
+		if (metric != EXPANN_METRIC_L2 && metric != EXPANN_METRIC_IP) {
+			g_create_error = "metric must be EXPANN_METRIC_L2 or EXPANN_METRIC_IP for f32 rows";
+			return EXPANN_ERR_INVALID_ARG;
+		}
+	} else if (dtype == EXPANN_DTYPE_U8) {
+		if (metric != EXPANN_METRIC_L2) {
+			g_create_error = "uint8 rows support EXPANN_METRIC_L2 only (dist2_compressed)";
+			return EXPANN_ERR_INVALID_ARG;
+		}
+		int_mode = kU8L2;
+	} else if (dtype == EXPANN_DTYPE_I8) {
+		if (metric == EXPANN_METRIC_L2)
+			int_mode = kI8L2;
+		else if (metric == EXPANN_METRIC_IP)
+			int_mode = kI8IP;
+		else if (metric == EXPANN_METRIC_L2_I8_REFCOMPAT)
+			int_mode = kI8L2Ref;
+		else {
+			g_create_error = "unknown metric for int8 rows";
+			return EXPANN_ERR_INVALID_ARG;
+		}
+	} else {
+		g_create_error = "unknown dtype";
+		return EXPANN_ERR_INVALID_ARG;
 	}
-	if (metric != EXPANN_METRIC_L2 && metric != EXPANN_METRIC_IP) {
-		g_create_error = "metric must be EXPANN_METRIC_L2 or EXPANN_METRIC_IP for f32 rows";
+	if (int_mode >= 0 && dim % 64 != 0) {
+		g_create_error = "8-bit rows need dim % 64 == 0 (src/distance.h:29-53, antitopo_engine.h:726)";
 		return EXPANN_ERR_INVALID_ARG;
 	}
 	int ndev = expann_device_count();
@@ -471,9 +586,10 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		g_create_error = "device index out of range";
 		return EXPANN_ERR_INVALID_ARG;
 	}
-	if (!pick_scan_f32(dim, metric == EXPANN_METRIC_IP, 1, 0)) {
+	if ((int_mode < 0 && !pick_scan_f32(dim, metric == EXPANN_METRIC_IP, 1, 0)) ||
+	    (int_mode >= 0 && !pick_scan_i8(dim, int_mode, 1, 0))) {
 		g_create_error = "unsupported dim " + std::to_string(dim) +
-		                 " (built: 64,128,256,512,768,832,960,1024)";
+		                 " (built: f32 64,128,256,512,768,832,960,1024; 8-bit 64,128,256,768,960)";
 		return EXPANN_ERR_UNSUPPORTED;
 	}
 	expann_index* h = new expann_index();
@@ -481,7 +597,9 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	h->dtype = dtype;
 	h->metric = metric;
 	h->device = device;
-	h->elem = 4;
+	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : 1;
+	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : 4;
+	h->int_mode = int_mode;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -525,6 +643,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_total) hipFree(h->d_total);
 	if (h->h_flags) hipHostFree(h->h_flags);
 	if (h->d_q) hipFree(h->d_q);
+	if (h->d_q8) hipFree(h->d_q8);
 	if (h->d_ids) hipFree(h->d_ids);
 	if (h->d_dists) hipFree(h->d_dists);
 	if (h->ev_created)
@@ -608,7 +727,7 @@ int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_
 		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
 	HIP_TRY(h, hipSetDevice(h->device));
 	hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-	const size_t qbytes = (size_t)h->dim * h->elem;
+	const size_t qbytes = (size_t)h->dim * h->q_elem;
 	for (size_t q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
 		const size_t mm = std::min(kMaxQueriesPerPass, m - q0);
 		int rc = search_pass(h, (const char*)d_queries + q0 * qbytes, mm, k, d_ids + q0 * k,
@@ -632,7 +751,7 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 	if (!queries || !ids)
 		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
 	HIP_TRY(h, hipSetDevice(h->device));
-	const size_t qbytes = m * (size_t)h->dim * h->elem;
+	const size_t qbytes = m * (size_t)h->dim * h->q_elem;
 	if (qbytes > h->io_q_bytes) {
 		if (h->d_q) hipFree(h->d_q);
 		h->d_q = nullptr;
@@ -702,23 +821,49 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 		if (ids[i] < h->id_offset || ids[i] - h->id_offset >= h->n)
 			return h->fail(EXPANN_ERR_INVALID_ARG, "id out of range");
 	HIP_TRY(h, hipSetDevice(h->device));
-	const ScoreVariant* sv = nullptr;
-	for (const auto& v : kScoreF32)
-		if (v.d == h->dim && v.ip == (h->metric == EXPANN_METRIC_IP))
-			sv = &v;
-	if (!sv)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "no score kernel for this dim");
-	void *d_query = nullptr, *d_idl = nullptr, *d_sc = nullptr;
-	const size_t qb = (size_t)h->dim * h->elem;
+	void *d_query = nullptr, *d_idl = nullptr, *d_sc = nullptr, *d_q8s = nullptr;
+	uint32_t* d_bad = nullptr;
+	const size_t qb = (size_t)h->dim * h->q_elem;
 	HIP_TRY(h, hipMalloc(&d_query, qb));
 	HIP_TRY(h, hipMalloc(&d_idl, sizeof(uint64_t) * n_ids));
 	HIP_TRY(h, hipMalloc(&d_sc, sizeof(float) * n_ids));
 	HIP_TRY(h, hipMemcpyAsync(d_query, query, qb, hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(d_idl, ids, sizeof(uint64_t) * n_ids, hipMemcpyHostToDevice, h->stream));
-	ScoreIdsParams sp{h->d_base, d_query, (const uint64_t*)d_idl, h->id_offset, (uint32_t)n_ids,
-	                  (float*)d_sc};
 	const uint32_t blocks = (uint32_t)((n_ids + kRowsPerGroup - 1) / kRowsPerGroup);
-	hipLaunchKernelGGL(sv->fn, dim3(blocks), dim3(kBlock), 0, h->stream, sp);
+	uint32_t bad_host = 0;
+	if (h->dtype == EXPANN_DTYPE_F32) {
+		const ScoreVariant* sv = nullptr;
+		for (const auto& v : kScoreF32)
+			if (v.d == h->dim && v.ip == (h->metric == EXPANN_METRIC_IP))
+				sv = &v;
+		if (!sv)
+			return h->fail(EXPANN_ERR_UNSUPPORTED, "no score kernel for this dim");
+		ScoreIdsParams sp{h->d_base, d_query, (const uint64_t*)d_idl, h->id_offset,
+		                  (uint32_t)n_ids, (float*)d_sc};
+		hipLaunchKernelGGL(sv->fn, dim3(blocks), dim3(kBlock), 0, h->stream, sp);
+	} else {
+		const ScoreI8Variant* sv = nullptr;
+		for (const auto& v : kScoreI8)
+			if (v.d == h->dim && v.mode == h->int_mode)
+				sv = &v;
+		if (!sv)
+			return h->fail(EXPANN_ERR_UNSUPPORTED, "no 8-bit score kernel for this dim");
+		const void* qptr = d_query;
+		if (h->dtype == EXPANN_DTYPE_U8) {
+			HIP_TRY(h, hipMalloc(&d_q8s, (size_t)h->dim));
+			HIP_TRY(h, hipMalloc((void**)&d_bad, sizeof(uint32_t)));
+			HIP_TRY(h, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), h->stream));
+			hipLaunchKernelGGL(u8_query_prep_kernel, dim3((uint32_t)((h->dim + kBlock - 1) / kBlock)),
+			                   dim3(kBlock), 0, h->stream, (const float*)d_query, (size_t)h->dim,
+			                   (uint8_t*)d_q8s, d_bad);
+			HIP_TRY(h, hipMemcpyAsync(&bad_host, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost,
+			                          h->stream));
+			qptr = d_q8s;
+		}
+		ScoreIdsI8Params sp{h->d_base, qptr, (const uint64_t*)d_idl, h->id_offset, (uint32_t)n_ids,
+		                    (float*)d_sc};
+		hipLaunchKernelGGL(sv->fn, dim3(blocks), dim3(kBlock), 0, h->stream, sp);
+	}
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float> sc(n_ids);
 	HIP_TRY(h, hipMemcpyAsync(sc.data(), d_sc, sizeof(float) * n_ids, hipMemcpyDeviceToHost, h->stream));
@@ -726,6 +871,10 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 	hipFree(d_query);
 	hipFree(d_idl);
 	hipFree(d_sc);
+	if (d_q8s) hipFree(d_q8s);
+	if (d_bad) hipFree(d_bad);
+	if (bad_host)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "query values outside [0,255] for the uint8 metric");
 	size_t kept = 0;
 	for (size_t i = 0; i < n_ids; ++i)  // src/quantizer.h:42-46: keep iff d < cutoff, order kept
 		if (sc[i] < cutoff) {

@@ -1,0 +1,109 @@
+"""GPU parity of the 8-bit paths: integer scores are exact, so ids and
+distances must be bit-identical to the oracle for every metric, including the reference's own
+wrapped int8 kernel (src/distance.h:29-53)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(base, metric, dtype):
+    from expann_amd import GpuBruteForceEngine
+    eng = GpuBruteForceEngine(base.shape[1], metric, dtype)
+    eng.store_many_vectors(base)
+    eng.build()
+    return eng
+
+
+def _check(oracle, eng, base, queries, k, ometric):
+    ids, dists = eng.query_k_batch(queries, k)
+    rids, rd = oracle.brute_force(base, queries, k, ometric, n_threads=8)
+    assert np.array_equal(ids, rids)
+    assert np.array_equal(dists.view(np.uint32), rd.view(np.uint32))
+
+
+def _sift_like(rng, n, d):
+    """SURVEY 8d's SIFT stand-in: clamp(round(|N(0,1)|*40), 0, 255)."""
+    return np.clip(np.round(np.abs(rng.standard_normal((n, d))) * 40), 0, 255)
+
+
+@pytest.mark.parametrize("n,d,m,k", [(5000, 128, 20, 10), (40000, 128, 7, 10), (3000, 64, 33, 5),
+                                     (2000, 256, 4, 10), (20000, 128, 1, 100)])
+def test_u8_compressed_l2(oracle, n, d, m, k):
+    """dist2_compressed (src/antitopo_engine.h:38-61): fp32 query truncated to integers against
+    uint8 rows.  Ties are frequent on integer data, so this also exercises the (score, id) rule."""
+    rng = np.random.RandomState(n + d)
+    base = _sift_like(rng, n, d).astype(np.uint8)
+    queries = (_sift_like(rng, m, d) + rng.uniform(0, 0.99, size=(m, d))).astype(np.float32)
+    queries = np.minimum(queries, np.float32(255.5))
+    eng = _engine(base, "l2", "u8")
+    _check(oracle, eng, base, queries, k, oracle.METRIC_L2_U8)
+    for tq in (1, 4, 16):
+        if d == 128:
+            eng.set_option("query_tile", tq)
+            _check(oracle, eng, base, queries, k, oracle.METRIC_L2_U8)
+    eng.close()
+
+
+def test_u8_rejects_queries_outside_8_bits(oracle):
+    from expann_amd._lib import ExpannError
+    base = np.zeros((2000, 128), np.uint8)
+    eng = _engine(base, "l2", "u8")
+    q = np.zeros((2, 128), np.float32)
+    q[1, 5] = 300.0
+    with pytest.raises(ExpannError):
+        eng.query_k_batch(q, 3)
+    q[1, 5] = -1.0
+    with pytest.raises(ExpannError):
+        eng.query_k_batch(q, 3)
+    eng.close()
+
+
+@pytest.mark.parametrize("metric,ometric", [("l2", "METRIC_L2_I8"), ("ip", "METRIC_IP_I8"),
+                                            ("l2_i8_refcompat", "METRIC_L2_I8_REFCOMPAT")])
+@pytest.mark.parametrize("n,d,m,k", [(6000, 128, 19, 10), (3000, 768, 9, 10), (30000, 64, 5, 10)])
+def test_int8_metrics(oracle, metric, ometric, n, d, m, k):
+    rng = np.random.RandomState(n * 3 + d)
+    base = rng.randint(-127, 128, size=(n, d)).astype(np.int8)
+    queries = rng.randint(-127, 128, size=(m, d)).astype(np.int8)
+    eng = _engine(base, metric, "i8")
+    _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
+    eng.close()
+
+
+def test_int8_refcompat_differs_from_true_l2_like_the_reference(oracle):
+    """On [0,127] data the reference kernel's ranking is NOT the L2 ranking; both
+    are available and both match their oracle."""
+    rng = np.random.RandomState(31)
+    base = rng.randint(0, 128, size=(4000, 128)).astype(np.int8)
+    queries = rng.randint(0, 128, size=(6, 128)).astype(np.int8)
+    e1 = _engine(base, "l2", "i8")
+    e2 = _engine(base, "l2_i8_refcompat", "i8")
+    i1, _ = e1.query_k_batch(queries, 10)
+    i2, d2 = e2.query_k_batch(queries, 10)
+    assert not np.array_equal(i1, i2)
+    rids, rd = oracle.brute_force(base, queries, 10, oracle.METRIC_L2_I8_REFCOMPAT)
+    assert np.array_equal(i2, rids) and np.array_equal(d2, rd)
+    e1.close()
+    e2.close()
+
+
+def test_score_ids_8bit(oracle):
+    rng = np.random.RandomState(77)
+    base = _sift_like(rng, 3000, 128).astype(np.uint8)
+    q = (_sift_like(rng, 1, 128)[0] + 0.5).astype(np.float32)
+    eng = _engine(base, "l2", "u8")
+    ids = rng.randint(0, 3000, size=120).astype(np.uint64)
+    cutoff = 150000.0
+    kept, sc = eng.score_ids(q, ids, cutoff)
+    okept, osc = oracle.filter_by_score(base, q, ids, cutoff, oracle.METRIC_L2_U8)
+    assert np.array_equal(kept, okept) and np.array_equal(sc, osc)
+    eng.close()
+    b8 = rng.randint(-127, 128, size=(2000, 768)).astype(np.int8)
+    q8 = rng.randint(-127, 128, size=768).astype(np.int8)
+    eng = _engine(b8, "ip", "i8")
+    ids = rng.randint(0, 2000, size=50).astype(np.uint64)
+    kept, sc = eng.score_ids(q8, ids)
+    okept, osc = oracle.filter_by_score(b8, q8, ids, float("inf"), oracle.METRIC_IP_I8)
+    assert np.array_equal(kept, okept) and np.array_equal(sc, osc)
+    eng.close()
