@@ -17,6 +17,7 @@
 
 #include "scan_f32.hpp"
 #include "scan_gemm_f32.hpp"
+#include "scan_gemm_i8.hpp"
 #include "scan_int8.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
@@ -62,7 +63,9 @@ struct expann_index {
 	unsigned long long* d_total = nullptr;
 	uint32_t* h_flags = nullptr;     // pinned [4]
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
-	float* d_theta = nullptr;        // [m_alloc]
+	float* d_theta = nullptr;        // [m_alloc] (int32 thetas for the 8-bit GEMM form)
+	int* d_bias_i = nullptr;         // [n] sum b^2 per row (8-bit L2 GEMM form), built lazily
+	int* d_qself = nullptr;          // [m_alloc]
 	void* d_q = nullptr;             // host-API staging
 	uint64_t* d_ids = nullptr;
 	float* d_dists = nullptr;
@@ -250,8 +253,11 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		if (h->d_tau[0]) hipFree(h->d_tau[0]);
 		if (h->d_tau[1]) hipFree(h->d_tau[1]);
 		if (h->d_theta) hipFree(h->d_theta);
+		if (h->d_qself) hipFree(h->d_qself);
 		h->d_cnt = nullptr;
 		h->d_theta = nullptr;
+		h->d_qself = nullptr;
+		HIP_TRY(h, hipMalloc(&h->d_qself, sizeof(int) * m));
 		h->d_tau[0] = h->d_tau[1] = nullptr;
 		HIP_TRY(h, hipMalloc(&h->d_theta, sizeof(float) * m));
 		HIP_TRY(h, hipMalloc(&h->d_cnt, sizeof(uint32_t) * m));
@@ -312,6 +318,47 @@ int ensure_bnorm(expann_index* h, const GemmVariant* gv, hipStream_t st) {
 	return EXPANN_OK;
 }
 
+// ---- 8-bit GEMM form (int8 MFMA) -----------------------------------------------------------
+using GemmI8Fn = void (*)(GemmI8Params);
+using SelfI8Fn = void (*)(const void*, uint32_t, int*);
+using ThetaI8Fn = void (*)(const void*, uint32_t, const float*, int*, int*);
+struct GemmI8Variant {
+	int d, mode;
+	GemmI8Fn scan;
+	SelfI8Fn self;
+	ThetaI8Fn theta;
+	const char* name;
+};
+#define GEMM_I8(D, MODE, MN) {D, MODE, scan_gemm_i8_kernel<D, MODE>, row_self_i8_kernel<D, MODE>, \
+	query_theta_i8_kernel<D, MODE>, "scan_gemm_i8<" #D "," MN ">"}
+const GemmI8Variant kGemmI8[] = {
+    GEMM_I8(128, kU8L2, "U8L2"), GEMM_I8(128, kI8L2, "I8L2"), GEMM_I8(128, kI8IP, "I8IP"),
+    GEMM_I8(256, kU8L2, "U8L2"), GEMM_I8(256, kI8L2, "I8L2"), GEMM_I8(256, kI8IP, "I8IP"),
+    GEMM_I8(768, kU8L2, "U8L2"), GEMM_I8(768, kI8L2, "I8L2"), GEMM_I8(768, kI8IP, "I8IP")};
+#undef GEMM_I8
+
+const GemmI8Variant* pick_gemm_i8(const expann_index* h, size_t m) {
+	if (h->opt_scan_kernel == 1 || h->dtype == EXPANN_DTYPE_F32)
+		return nullptr;
+	if (h->opt_scan_kernel == 0 && (m < 96 || h->n < 4096))
+		return nullptr;
+	for (const auto& v : kGemmI8)
+		if (v.d == h->dim && v.mode == h->int_mode)
+			return &v;
+	return nullptr;
+}
+
+int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
+	if (h->d_bias_i || h->int_mode == kI8IP)
+		return EXPANN_OK;
+	HIP_TRY(h, hipMalloc(&h->d_bias_i, sizeof(int) * h->n));
+	const uint32_t blocks = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
+	hipLaunchKernelGGL(gv->self, dim3(blocks), dim3(kBlock), 0, st, (const void*)h->d_base,
+	                   (uint32_t)h->n, h->d_bias_i);
+	HIP_TRY(h, hipGetLastError());
+	return EXPANN_OK;
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
@@ -364,8 +411,15 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		                                           std::to_string(kMaxCap / 2) + ")");
 	const int cus = num_cus(h->device);
 	const GemmVariant* gv = pick_gemm(h, m);
-	if (h->opt_scan_kernel == 2 && !gv)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "GEMM-form scan: f32 L2 with dim 64 or 128 only");
+	const GemmI8Variant* gvi = pick_gemm_i8(h, m);
+	if (h->opt_scan_kernel == 2 && !gv && !gvi)
+		return h->fail(EXPANN_ERR_UNSUPPORTED,
+		               "GEMM-form scan: f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
+	if (gvi) {
+		int rc = ensure_bias_i8(h, gvi, st);
+		if (rc != EXPANN_OK)
+			return rc;
+	}
 	if (gv) {
 		int rc = ensure_bnorm(h, gv, st);
 		if (rc != EXPANN_OK)
@@ -455,6 +509,51 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				passes = gp.n_qtiles;
 				kname = gv->name;
 				qt_used = kGemmTQ;
+			} else if (gvi && !first) {
+				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+				                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,
+				                   (int*)h->d_theta, h->d_qself);
+				const uint32_t tb = (uint32_t)gemm_i8_tb(h->dim);
+				GemmI8Params gp{};
+				gp.base = h->d_base;
+				gp.bias = h->d_bias_i;
+				gp.n_rows = (uint32_t)h->n;
+				const uint32_t n_tiles = (uint32_t)((h->n + tb - 1) / tb);
+				gp.n_tiles_sel = last ? n_tiles
+				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + tb - 1) / tb);
+				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
+				gp.n_qtiles = (uint32_t)((m + kGemmI8TQ - 1) / kGemmI8TQ);
+				gp.queries = d_queries;
+				gp.theta = (const int*)h->d_theta;
+				gp.qself = h->d_qself;
+				gp.m = (uint32_t)m;
+				gp.cand_cnt = h->d_cnt;
+				gp.cand = h->d_cand;
+				gp.cap = cap;
+				uint32_t gchunks = 1;
+				{
+					const uint32_t gmax = std::max<uint32_t>(1, gp.n_tiles_sel / 4);
+					double best = 1e300;
+					for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 4096); ++g) {
+						const uint32_t steps = (gp.n_tiles_sel + g - 1) / g;
+						const uint64_t blocks = (uint64_t)g * gp.n_qtiles;
+						const uint64_t rounds = (blocks + cus - 1) / cus;
+						const double cost = (double)rounds * (steps + 2.0);
+						if (cost < best * 0.999) {
+							best = cost;
+							gchunks = g;
+						}
+					}
+				}
+				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
+				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
+				if (timed)
+					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+				hipLaunchKernelGGL(gvi->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+				                   2 * tb * h->dim, st, gp);
+				passes = gp.n_qtiles;
+				kname = gvi->name;
+				qt_used = kGemmI8TQ;
 			} else {
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
@@ -623,6 +722,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 				delete h;
 				return EXPANN_ERR_HIP;
 			}
+	for (const auto& v : kGemmI8)
+		if (v.d == dim && v.mode == int_mode)
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        2 * gemm_i8_tb(dim) * dim) != hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_i8_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
 	*out = h;
 	return EXPANN_OK;
 }
@@ -639,6 +747,8 @@ void expann_destroy(expann_index* h) {
 	if (h->d_tau[1]) hipFree(h->d_tau[1]);
 	if (h->d_overflow) hipFree(h->d_overflow);
 	if (h->d_bnorm) hipFree(h->d_bnorm);
+	if (h->d_bias_i) hipFree(h->d_bias_i);
+	if (h->d_qself) hipFree(h->d_qself);
 	if (h->d_theta) hipFree(h->d_theta);
 	if (h->d_total) hipFree(h->d_total);
 	if (h->h_flags) hipHostFree(h->h_flags);
@@ -703,6 +813,10 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 	if (h->d_bnorm) {
 		hipFree(h->d_bnorm);
 		h->d_bnorm = nullptr;
+	}
+	if (h->d_bias_i) {
+		hipFree(h->d_bias_i);
+		h->d_bias_i = nullptr;
 	}
 	h->d_base = const_cast<void*>(d_rows);
 	h->owns_base = false;

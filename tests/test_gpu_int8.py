@@ -107,3 +107,29 @@ def test_score_ids_8bit(oracle):
     okept, osc = oracle.filter_by_score(b8, q8, ids, float("inf"), oracle.METRIC_IP_I8)
     assert np.array_equal(kept, okept) and np.array_equal(sc, osc)
     eng.close()
+
+
+@pytest.mark.parametrize("dtype,metric,ometric,d", [
+    ("u8", "l2", "METRIC_L2_U8", 128), ("u8", "l2", "METRIC_L2_U8", 256),
+    ("i8", "l2", "METRIC_L2_I8", 128), ("i8", "ip", "METRIC_IP_I8", 768),
+    ("i8", "l2", "METRIC_L2_I8", 768), ("i8", "ip", "METRIC_IP_I8", 256),
+])
+@pytest.mark.parametrize("n,m,k", [(20000, 130, 10), (4099, 100, 17), (300, 129, 10)])
+def test_gemm_form_int8_mfma(oracle, dtype, metric, ometric, d, n, m, k):
+    """scan_kernel=2 forces the int8-MFMA GEMM-form filter (exact in integers, no re-rank)."""
+    rng = np.random.RandomState(n + d + m)
+    if dtype == "u8":
+        base = _sift_like(rng, n, d).astype(np.uint8)
+        queries = np.minimum(_sift_like(rng, m, d) + rng.uniform(0, 0.99, size=(m, d)),
+                             255.5).astype(np.float32)
+    else:
+        base = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
+        queries = rng.randint(-128, 128, size=(m, d)).astype(np.int8)
+    eng = _engine(base, metric, dtype)
+    eng.set_option("scan_kernel", 2)
+    eng.set_profiling(True)
+    _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
+    prof = eng.get_profile()
+    if n > 1024:
+        assert prof["scan_kernel"].startswith("scan_gemm_i8"), prof["scan_kernel"]
+    eng.close()
