@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (155 measured)
+MFMA_I8_PEAK_TOPS = 5033.0     # int8 MFMA = 2x the bf16 rate per clock (~2.5 PF dense bf16):
+                               # 2048 ops/clk/SIMD x 1024 SIMDs x 2.4 GHz
 
 
 def parse():
@@ -34,14 +36,23 @@ def parse():
     ap.add_argument("--m", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "i8", "u8"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="preset: c2 = BASELINE configs[1] (default, the headline metric); "
+                         "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric)")
     ap.add_argument("--query-tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="rough budget of the CPU baseline leg")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "c5":
+        a.dtype, a.metric = "i8", "ip"
+        if a.n == 1_000_000 and a.d == 128:
+            a.n, a.d = 10_000_000, 768
+    return a
 
 
-def cpu_baseline(base_host, queries_host, k, budget_s):
+def cpu_baseline(base_host, queries_host, k, budget_s, metric_name="METRIC_L2_F32"):
     """Time the CPU oracle (kind 'port': oracle/expann_oracle.c, a restatement of
     src/brute_force_engine.h:28-46 + src/distance.h:136-147) on this host's cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -68,11 +79,11 @@ def cpu_baseline(base_host, queries_host, k, budget_s):
         pass
     # 1 thread: the reference's execution model (src/basic_bench.h:83-84)
     t0 = time.perf_counter()
-    oc.brute_force(base_host, queries_host[:2], k, oc.METRIC_L2_F32, 1, _lib_override=lib)
+    oc.brute_force(base_host, queries_host[:2], k, getattr(oc, metric_name), 1, _lib_override=lib)
     t1 = (time.perf_counter() - t0) / 2
     n1 = max(2, min(32, int(budget_s * 0.3 / max(t1, 1e-6))))
     t0 = time.perf_counter()
-    oc.brute_force(base_host, queries_host[:n1], k, oc.METRIC_L2_F32, 1, _lib_override=lib)
+    oc.brute_force(base_host, queries_host[:n1], k, getattr(oc, metric_name), 1, _lib_override=lib)
     qps1 = n1 / (time.perf_counter() - t0)
     # all cores, queries partitioned over threads (extension).  The scan is DRAM
     # bound, so more threads than memory channels can be slower: try a few pool sizes and
@@ -84,7 +95,7 @@ def cpu_baseline(base_host, queries_host, k, budget_s):
         nq = int(min(len(queries_host), max(c, per * qps1 * min(c, 16) * 0.5)))
         nq = max(c, (nq // c) * c)
         t0 = time.perf_counter()
-        oc.brute_force(base_host, queries_host[:nq], k, oc.METRIC_L2_F32, c, _lib_override=lib)
+        oc.brute_force(base_host, queries_host[:nq], k, getattr(oc, metric_name), c, _lib_override=lib)
         q = nq / (time.perf_counter() - t0)
         if q > best[0]:
             best = (q, c, nq)
@@ -148,11 +159,22 @@ def main():
     lo, hi = shard_range(a.n, rank, G)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
-    g.manual_seed(4321)
-    queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
+    if a.dtype == "f32":
+        base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
+        g.manual_seed(4321)
+        queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
+    elif a.dtype == "i8":   # int8 uniform in [-127, 127]
+        base = torch.randint(-127, 128, (hi - lo, a.d), device=dev, dtype=torch.int8, generator=g)
+        g.manual_seed(4321)
+        queries = torch.randint(-127, 128, (a.m, a.d), device=dev, dtype=torch.int8, generator=g)
+    else:                   # SURVEY 8d C4 stand-in: clamp(round(|N(0,1)|*40), 0, 255)
+        base = torch.randn(hi - lo, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
+            .clamp_(0, 255).to(torch.uint8)
+        g.manual_seed(4321)
+        queries = torch.randn(a.m, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
+            .clamp_(0, 255).to(torch.float32)
 
-    eng = GpuBruteForceEngine(a.d, a.metric, device=local_rank)
+    eng = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
     eng.set_base_device(base.data_ptr(), hi - lo, lo)
     if a.query_tile:
         eng.set_option("query_tile", a.query_tile)
@@ -212,15 +234,21 @@ def main():
         scan_ms = prof["scan_ms"] / launches
         n_local = hi - lo
         passes = prof["scan_query_tiles"] / launches
-        alg_bytes = passes * n_local * a.d * 4          # one pass of a query tile = N*d*4 B
+        esz = 4 if a.dtype == "f32" else 1
+        alg_bytes = passes * n_local * a.d * esz        # one pass of a query tile = N*d*sizeof B
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         default_cfg = (a.n, a.d, a.m, a.k, G) == (1_000_000, 128, 10_000, 10, 1)
         traffic, traffic_src = profiled_traffic(prof["scan_kernel"]) if default_cfg else (None, None)
         hbm_view = {"achieved_GBps": round(achieved, 1), "frac_of_8TBps": round(achieved / HBM_PEAK_GBS, 4),
                     "passes_per_launch": passes, "query_tile": int(prof["query_tile"]),
-                    "single_pass_equiv_GBps": round(n_local * a.d * 4 / (scan_ms * 1e-3) / 1e9, 2)
+                    "single_pass_equiv_GBps": round(n_local * a.d * esz / (scan_ms * 1e-3) / 1e9, 2)
                     if scan_ms > 0 else 0.0}
-        if prof["scan_kernel"].startswith("scan_gemm"):
+        if prof["scan_kernel"].startswith("scan_gemm_i8"):
+            ops = 2.0 * n_local * a.d * a.m             # C5 2*N*d*m int ops
+            tops = ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS,
+                        "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
+        elif prof["scan_kernel"].startswith("scan_gemm"):
             # GEMM-form filter on the matrix cores: algorithmic flops = 2*N*d*m
             flops = 2.0 * n_local * a.d * a.m
             tf = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
@@ -236,19 +264,25 @@ def main():
             "kernel_ms": round(scan_ms, 4), "launches": int(launches),
             "algorithmic_bytes_per_launch": alg_bytes, "hbm_view": hbm_view,
             "candidates_per_query": round(prof["candidates"] / a.m, 1)})
-        out = {"metric": "queries/sec at recall@10=1.0 (exact brute force), 1Mxd128 fp32, k=10",
+        desc = {"f32": "fp32", "i8": "int8", "u8": "uint8"}[a.dtype]
+        shape = f"{a.n // 1_000_000}M" if a.n % 1_000_000 == 0 else str(a.n)
+        out = {"metric": f"queries/sec at recall@{a.k}=1.0 (exact brute force), {shape}xd{a.d} {desc}, k={a.k}",
                "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"brute_force_engine L2 N={a.n} d={a.d} fp32, "
-                                      f"{a.m} batched queries, k={a.k} (BASELINE configs[1])",
+               "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"brute_force_engine {a.metric.upper()} N={a.n} d={a.d} {desc}, "
+                                      f"{a.m} batched queries, k={a.k} (BASELINE "
+                                      f"{'configs[1]' if a.workload == 'c2' else 'configs[4]'})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
                           "sharding": f"rows/{G}" if G > 1 else "none"},
                "roofline": roofline}
         if G == 1 and not a.no_cpu_baseline:
             try:
+                mname = {("f32", "l2"): "METRIC_L2_F32", ("f32", "ip"): "METRIC_IP_F32",
+                         ("i8", "l2"): "METRIC_L2_I8", ("i8", "ip"): "METRIC_IP_I8",
+                         ("u8", "l2"): "METRIC_L2_U8"}[(a.dtype, a.metric)]
                 out["cpu_baseline"] = cpu_baseline(base.cpu().numpy(), queries.cpu().numpy(), a.k,
-                                                   a.cpu_seconds)
+                                                   a.cpu_seconds, mname)
             except Exception as e:  # the baseline is a reported extra, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
                                        "kind": "port", "sample": f"failed: {e}"}

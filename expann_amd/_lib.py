@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "expann_last_error", "expann_add", "expann_build", "expann_set_base_device", "expann_size",
     "expann_search", "expann_search_device", "expann_merge_topk_device", "expann_score_ids",
     "expann_set_profiling", "expann_get_profile", "expann_set_option",
+    "expann_quantize_simple_u8_device", "expann_quantize_ranged_q8_device",
 ]
 
 
@@ -71,6 +72,10 @@ def load():
     L.expann_merge_topk_device.argtypes = [C.c_int, vp, vp, sz, sz, sz, vp, vp, vp]
     L.expann_score_ids.restype = C.c_int
     L.expann_score_ids.argtypes = [vp, vp, vp, sz, C.c_float, vp, vp, C.POINTER(sz)]
+    L.expann_quantize_simple_u8_device.restype = C.c_int
+    L.expann_quantize_simple_u8_device.argtypes = [C.c_int, vp, sz, vp, vp]
+    L.expann_quantize_ranged_q8_device.restype = C.c_int
+    L.expann_quantize_ranged_q8_device.argtypes = [C.c_int, vp, sz, vp, vp, vp]
     L.expann_set_profiling.restype = C.c_int
     L.expann_set_profiling.argtypes = [vp, C.c_int]
     L.expann_get_profile.restype = C.c_int

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "quantize.hpp"
 #include "scan_f32.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
@@ -997,6 +998,64 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 			++kept;
 		}
 	*n_kept = kept;
+	return EXPANN_OK;
+}
+
+int expann_quantize_simple_u8_device(int device, const float* d_rows, size_t n_values,
+                                     uint8_t* d_out, void* stream) {
+	if (!d_rows || !d_out) {
+		g_create_error = "expann_quantize_simple_u8_device: NULL pointer";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (n_values == 0)
+		return EXPANN_OK;
+	if (hipSetDevice(device) != hipSuccess) {
+		g_create_error = "hipSetDevice failed";
+		return EXPANN_ERR_HIP;
+	}
+	hipLaunchKernelGGL(quantize_simple_u8_kernel, dim3((uint32_t)((n_values + kBlock - 1) / kBlock)),
+	                   dim3(kBlock), 0, (hipStream_t)stream, d_rows, n_values, d_out);
+	if (hipGetLastError() != hipSuccess) {
+		g_create_error = "quantize_simple_u8_kernel launch failed";
+		return EXPANN_ERR_HIP;
+	}
+	return EXPANN_OK;
+}
+
+int expann_quantize_ranged_q8_device(int device, const float* d_rows, size_t n_values,
+                                     int8_t* d_out, float* d_scale_offset, void* stream) {
+	if (!d_rows || !d_out || !d_scale_offset || n_values == 0) {
+		g_create_error = "expann_quantize_ranged_q8_device: bad arguments";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		g_create_error = "hipSetDevice failed";
+		return EXPANN_ERR_HIP;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	uint32_t* d_mm = nullptr;
+	if (hipMalloc(&d_mm, 2 * sizeof(uint32_t)) != hipSuccess) {
+		g_create_error = "hipMalloc failed";
+		return EXPANN_ERR_HIP;
+	}
+	// min starts at FLT_MAX, max at FLT_MIN (smallest positive normal): src/quantizer.h:217-218
+	const uint32_t init[2] = {float_to_ordered(3.402823466e+38f), float_to_ordered(1.175494351e-38f)};
+	hipError_t e = hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);  // `init` is a stack buffer
+	if (e == hipSuccess) {
+		const uint32_t blocks = (uint32_t)std::min<size_t>((n_values + kBlock - 1) / kBlock, 4096);
+		hipLaunchKernelGGL(minmax_f32_kernel, dim3(blocks), dim3(kBlock), 0, st, d_rows, n_values, d_mm);
+		hipLaunchKernelGGL(quantize_ranged_q8_kernel, dim3((uint32_t)((n_values + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, d_rows, n_values, (const uint32_t*)d_mm, d_out,
+		                   d_scale_offset);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+	}
+	hipFree(d_mm);
+	if (e != hipSuccess) {
+		g_create_error = std::string("expann_quantize_ranged_q8_device: ") + hipGetErrorString(e);
+		return EXPANN_ERR_HIP;
+	}
 	return EXPANN_OK;
 }
 

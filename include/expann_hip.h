@@ -106,6 +106,16 @@ int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* 
 int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, size_t n_ids,
                      float cutoff, uint64_t* kept_ids, float* kept_scores, size_t* n_kept);
 
+/* quantiser builds on device buffers (src/quantizer.h) -------------------------------- */
+/* quantizer_simple<uint8_t>::build (src/quantizer.h:132-141): out[i] = uint8_t(in[i]), no
+ * scaling; defined for 0 <= in[i] < 256.  Asynchronous on `stream`. */
+int expann_quantize_simple_u8_device(int device, const float* d_rows, size_t n_values,
+                                     uint8_t* d_out, void* stream);
+/* quantizer_ranged_q8::build (src/quantizer.h:213-232, :196-200): global affine int8 in
+ * [0,127]; d_scale_offset[0..1] receive scale_factor and offset.  Synchronises `stream`. */
+int expann_quantize_ranged_q8_device(int device, const float* d_rows, size_t n_values,
+                                     int8_t* d_out, float* d_scale_offset, void* stream);
+
 /* profiling ------------------------------------------------------------------------- */
 typedef struct expann_profile {
 	uint64_t scan_launches;   /* launches of the full-base scan kernel since reset      */

@@ -133,3 +133,33 @@ def test_gemm_form_int8_mfma(oracle, dtype, metric, ometric, d, n, m, k):
     if n > 1024:
         assert prof["scan_kernel"].startswith("scan_gemm_i8"), prof["scan_kernel"]
     eng.close()
+
+
+def test_quantizer_builds_on_device(oracle):
+    """quantizer_simple<uint8_t> (cast) and quantizer_ranged_q8 (affine int8) vs the oracle."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from expann_amd import _lib
+    L = _lib.load()
+    rng = np.random.RandomState(12)
+    x = np.clip(np.abs(rng.standard_normal((500, 128))) * 40, 0, 255.9).astype(np.float32)
+    want = np.empty(x.size, np.uint8)
+    oracle.lib().oracle_quantize_simple_u8(x.ctypes.data, x.size, want.ctypes.data)
+    dx = torch.from_numpy(x).cuda()
+    out = torch.empty(x.size, dtype=torch.uint8, device="cuda")
+    assert L.expann_quantize_simple_u8_device(0, dx.data_ptr(), x.size, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    for scale in (1.0, 37.5, 1e-3):
+        y = (rng.standard_normal((300, 64)) * scale).astype(np.float32)
+        q8 = np.empty(y.size, np.int8)
+        sf, off = C.c_float(), C.c_float()
+        oracle.lib().oracle_quantize_ranged_q8(y.ctypes.data, 300, 64, q8.ctypes.data,
+                                               C.byref(sf), C.byref(off))
+        dy = torch.from_numpy(y).cuda()
+        o8 = torch.empty(y.size, dtype=torch.int8, device="cuda")
+        so = torch.empty(2, dtype=torch.float32, device="cuda")
+        assert L.expann_quantize_ranged_q8_device(0, dy.data_ptr(), y.size, o8.data_ptr(),
+                                                  so.data_ptr(), None) == 0
+        assert np.array_equal(o8.cpu().numpy(), q8)
+        assert so.cpu().numpy()[0] == np.float32(sf.value) and so.cpu().numpy()[1] == np.float32(off.value)
