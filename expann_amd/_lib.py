@@ -19,6 +19,8 @@ ABI_SYMBOLS = [
     "expann_search", "expann_search_device", "expann_merge_topk_device", "expann_score_ids",
     "expann_set_profiling", "expann_get_profile", "expann_set_option",
     "expann_quantize_simple_u8_device", "expann_quantize_ranged_q8_device",
+    "expann_graph_create", "expann_graph_destroy", "expann_graph_last_error",
+    "expann_graph_search", "expann_graph_last_kernel_ms",
 ]
 
 
@@ -76,6 +78,17 @@ def load():
     L.expann_quantize_simple_u8_device.argtypes = [C.c_int, vp, sz, vp, vp]
     L.expann_quantize_ranged_q8_device.restype = C.c_int
     L.expann_quantize_ranged_q8_device.argtypes = [C.c_int, vp, sz, vp, vp, vp]
+    L.expann_graph_create.restype = C.c_int
+    L.expann_graph_create.argtypes = [C.c_int, C.c_int, vp, sz, C.c_uint32, C.c_uint32, vp, vp,
+                                      C.POINTER(vp)]
+    L.expann_graph_destroy.restype = None
+    L.expann_graph_destroy.argtypes = [vp]
+    L.expann_graph_last_error.restype = C.c_char_p
+    L.expann_graph_last_error.argtypes = [vp]
+    L.expann_graph_search.restype = C.c_int
+    L.expann_graph_search.argtypes = [vp, vp, sz, sz, sz, C.c_int, vp, vp, vp]
+    L.expann_graph_last_kernel_ms.restype = C.c_double
+    L.expann_graph_last_kernel_ms.argtypes = [vp]
     L.expann_set_profiling.restype = C.c_int
     L.expann_set_profiling.argtypes = [vp, C.c_int]
     L.expann_get_profile.restype = C.c_int

@@ -106,6 +106,28 @@ int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* 
 int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, size_t n_ids,
                      float cutoff, uint64_t* kept_ids, float* kept_scores, size_t* n_kept);
 
+/* graph search (antitopo_engine, query side) --------------------------------------------- */
+typedef struct expann_graph expann_graph;
+/* Upload a built graph (replaces the tail of antitopo_engine::_build, src/antitopo_engine.h:
+ * 467-493, after deserialize :994-1074): `vectors` [n][dim] fp32 (all_entries), CSR adjacency
+ * per layer as flattened by include/expann/antitopo_index.h (hadj_flat): layer_offsets is
+ * [n_layers][n+1] into `neighbours`; layer 0 is hadj_bottom.  Host arrays, copied. */
+int expann_graph_create(int dim, int device, const float* vectors, size_t n, uint32_t n_layers,
+                        uint32_t starting_vertex, const uint64_t* layer_offsets,
+                        const uint32_t* neighbours, expann_graph** out);
+void expann_graph_destroy(expann_graph* g);
+const char* expann_graph_last_error(const expann_graph* g);
+/* antitopo_engine::_query_k for a batch (src/antitopo_engine.h:853-928): greedy descent, then
+ * the bottom-layer best-first search with queue size ef_search (:495-708), or with
+ * use_compression != 0 over uint8 rows + final fp32 re-score (:710-851).  Host buffers:
+ * ids[m][k] / dists[m][k] padded with UINT64_MAX / +inf; distcomps[m] (RECORD_STATS'
+ * num_distcomps per query, :125-129) may be NULL. */
+int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t k,
+                        size_t ef_search, int use_compression, uint64_t* ids, float* dists,
+                        uint32_t* distcomps);
+/* device time of the last expann_graph_search's traversal kernel, milliseconds */
+double expann_graph_last_kernel_ms(const expann_graph* g);
+
 /* quantiser builds on device buffers (src/quantizer.h) -------------------------------- */
 /* quantizer_simple<uint8_t>::build (src/quantizer.h:132-141): out[i] = uint8_t(in[i]), no
  * scaling; defined for 0 <= in[i] < 256.  Asynchronous on `stream`. */

@@ -129,6 +129,27 @@ size_t oracle_filter_by_score(const void* base, size_t d, const void* query, int
 /* src/basic_bench.h:116-121,143 recall = #(ans ∩ expected) / (m*k). */
 double oracle_recall(const uint64_t* ans, const uint64_t* expected, size_t m, size_t k);
 
+/* ---- graph search (antitopo_engine, query side) ----------------------------------------
+ * PARITY UNPINNED: src/antitopo_engine.h needs Eigen + nlohmann json and cannot be built
+ * here.  The restatement follows the source line by line, including libstdc++'s
+ * push_heap / pop_heap / make_heap element movement (the reference's priority queues compare
+ * .first only, so equal distances come out in heap order). */
+typedef struct oracle_graph oracle_graph;
+/* Load an index in the reference's binary layout (src/antitopo_engine.h:994-1074). */
+oracle_graph* oracle_graph_load(const char* path);
+void oracle_graph_destroy(oracle_graph* g);
+size_t oracle_graph_size(const oracle_graph* g);
+size_t oracle_graph_dim(const oracle_graph* g);
+const float* oracle_graph_vectors(const oracle_graph* g);
+/* src/antitopo_engine.h:853-928 _query_k: greedy descent through the upper layers (:863-902),
+ * then query_k_at_layer<true,false,false> (:495-708) or, with use_compression,
+ * query_k_bottom_compressed (:710-851) over quantizer_simple<uint8_t> rows (:132-141) with the
+ * final fp32 re-score (:845-848); truncated to k.  Returns the number of ids written; dists
+ * receive the .first values of the returned pairs; *n_distcomps the RECORD_STATS counter. */
+size_t oracle_graph_query_k(oracle_graph* g, const float* q, size_t k, size_t ef_search,
+                            int use_compression, uint64_t* ids, float* dists,
+                            uint64_t* n_distcomps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,8 @@ def build(arch_flags=None, out_dir=None):
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "liboracle_native.so")
     cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-fno-fast-math", "-ffp-contract=off", "-shared",
-           "-o", out, os.path.join(_HERE, "expann_oracle.c"), "-lm", "-lpthread"]
+           "-o", out, os.path.join(_HERE, "expann_oracle.c"),
+           os.path.join(_HERE, "expann_oracle_graph.c"), "-lm", "-lpthread"]
     cmd[2:2] = list(arch_flags or ["-march=x86-64-v3"])
     subprocess.check_call(cmd)
     return out
@@ -82,6 +83,19 @@ def _sig(lib):
     lib.oracle_filter_by_score.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
                                            C.c_void_p]
+    lib.oracle_graph_load.restype = C.c_void_p
+    lib.oracle_graph_load.argtypes = [C.c_char_p]
+    lib.oracle_graph_destroy.restype = None
+    lib.oracle_graph_destroy.argtypes = [C.c_void_p]
+    lib.oracle_graph_size.restype = C.c_size_t
+    lib.oracle_graph_size.argtypes = [C.c_void_p]
+    lib.oracle_graph_dim.restype = C.c_size_t
+    lib.oracle_graph_dim.argtypes = [C.c_void_p]
+    lib.oracle_graph_vectors.restype = C.c_void_p
+    lib.oracle_graph_vectors.argtypes = [C.c_void_p]
+    lib.oracle_graph_query_k.restype = C.c_size_t
+    lib.oracle_graph_query_k.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
     lib.oracle_recall.restype = C.c_double
     lib.oracle_recall.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
     return lib
@@ -234,3 +248,39 @@ def ref_topk_run(k, dists, ids, discard_goal=-1):
     return dict(is_good=is_good, size_after=size_after, worst_after=worst_after,
                 worst_val_after=worst_val_after, at_capacity_after=at_cap,
                 out_ids=out_ids[:cnt], out_dists=out_d[:cnt])
+
+
+class Graph:
+    """oracle_graph_* (restatement of the query side of src/antitopo_engine.h) over an index
+    file in the reference's binary layout."""
+
+    def __init__(self, path):
+        self._g = lib().oracle_graph_load(path.encode())
+        if not self._g:
+            raise IOError(f"cannot load index {path}")
+        self.n = lib().oracle_graph_size(self._g)
+        self.dim = lib().oracle_graph_dim(self._g)
+
+    def vectors(self):
+        p = C.cast(lib().oracle_graph_vectors(self._g), C.POINTER(C.c_float))
+        return np.ctypeslib.as_array(p, shape=(self.n, self.dim)).copy()
+
+    def query_k(self, queries, k, ef_search, use_compression=False):
+        """(ids[m,k] uint64 padded, dists[m,k], distcomps[m])"""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        m = queries.shape[0]
+        ids = np.full((m, k), 2 ** 64 - 1, dtype=np.uint64)
+        dists = np.full((m, k), np.inf, dtype=np.float32)
+        dc = np.zeros(m, dtype=np.uint64)
+        for i in range(m):
+            one = C.c_uint64()
+            lib().oracle_graph_query_k(self._g, queries[i].ctypes.data, k, ef_search,
+                                       int(use_compression), ids[i].ctypes.data,
+                                       dists[i].ctypes.data, C.byref(one))
+            dc[i] = one.value
+        return ids, dists, dc
+
+    def __del__(self):
+        if getattr(self, "_g", None):
+            lib().oracle_graph_destroy(self._g)
+            self._g = None
