@@ -18,6 +18,7 @@
 #include "graph_search.hpp"
 #include "quantize.hpp"
 #include "scan_f32.hpp"
+#include "scan_gemm_bf16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_int8.hpp"
@@ -65,6 +66,10 @@ struct expann_index {
 	unsigned long long* d_total = nullptr;
 	uint32_t* h_flags = nullptr;     // pinned [4]
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
+	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
+	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
+	void* d_q_split = nullptr;       // [m][2][dim] bf16
+	size_t q_split_bytes = 0;
 	float* d_theta = nullptr;        // [m_alloc] (int32 thetas for the 8-bit GEMM form)
 	int* d_bias_i = nullptr;         // [n] sum b^2 per row (8-bit L2 GEMM form), built lazily
 	int* d_qself = nullptr;          // [m_alloc]
@@ -74,7 +79,8 @@ struct expann_index {
 	size_t io_q_bytes = 0, io_out = 0;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
-	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter_f32), 2 GEMM form (MFMA)
+	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
+	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
 	bool profiling = false;
 	hipEvent_t ev[kEventPairs][2];
@@ -298,6 +304,15 @@ const GemmVariant kGemmF32[] = {
     {64, scan_gemm_f32_kernel<64>, row_norms_kernel<64>, query_theta_kernel<64>, "scan_gemm_f32<64>"},
     {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
 
+using GemmBf16Fn = void (*)(GemmBf16Params);
+struct GemmBf16Variant {
+	int d;
+	GemmBf16Fn scan;
+	const char* name;
+};
+const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16_kernel<64>, "scan_gemm_bf16x3<64>"},
+                                     {128, scan_gemm_bf16_kernel<128>, "scan_gemm_bf16x3<128>"}};
+
 const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
 		return nullptr;
@@ -309,14 +324,24 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	return nullptr;
 }
 
-int ensure_bnorm(expann_index* h, const GemmVariant* gv, hipStream_t st) {
-	if (h->d_bnorm)
-		return EXPANN_OK;
-	HIP_TRY(h, hipMalloc(&h->d_bnorm, sizeof(float) * h->n));
+int ensure_bnorm(expann_index* h, const GemmVariant* gv, bool bf16, hipStream_t st) {
+	float*& dst = bf16 ? h->d_bnorm_bf : h->d_bnorm;
 	const uint32_t blocks = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
-	hipLaunchKernelGGL(gv->norms, dim3(blocks), dim3(kBlock), 0, st, (const float*)h->d_base,
-	                   (uint32_t)h->n, 1.0f - gemm_filter_eps(h->dim), h->d_bnorm);
-	HIP_TRY(h, hipGetLastError());
+	if (!dst) {
+		HIP_TRY(h, hipMalloc(&dst, sizeof(float) * h->n));
+		const float eps = bf16 ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim);
+		hipLaunchKernelGGL(gv->norms, dim3(blocks), dim3(kBlock), 0, st, (const float*)h->d_base,
+		                   (uint32_t)h->n, 1.0f - eps, dst);
+		HIP_TRY(h, hipGetLastError());
+	}
+	if (bf16 && !h->d_base_split) {
+		const size_t nv = h->n * (size_t)h->dim;
+		HIP_TRY(h, hipMalloc(&h->d_base_split, nv * 4));
+		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, (const float*)h->d_base, h->n, h->dim,
+		                   (__bf16*)h->d_base_split);
+		HIP_TRY(h, hipGetLastError());
+	}
 	return EXPANN_OK;
 }
 
@@ -422,10 +447,31 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		if (rc != EXPANN_OK)
 			return rc;
 	}
+	const GemmBf16Variant* gvb = nullptr;
+	if (gv && h->opt_scan_kernel != 2)
+		for (const auto& v : kGemmBf16)
+			if (v.d == h->dim)
+				gvb = &v;
+	if (h->opt_scan_kernel == 3 && !gvb)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "bf16x3 GEMM-form scan: f32 L2 with dim 64 or 128 only");
 	if (gv) {
-		int rc = ensure_bnorm(h, gv, st);
+		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
 		if (rc != EXPANN_OK)
 			return rc;
+	}
+	if (gvb) {  // queries -> bf16 hi/lo planes
+		const size_t nv = m * (size_t)h->dim;
+		if (nv * 4 > h->q_split_bytes) {
+			if (h->d_q_split) hipFree(h->d_q_split);
+			h->d_q_split = nullptr;
+			h->q_split_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_q_split, nv * 4));
+			h->q_split_bytes = nv * 4;
+		}
+		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, (const float*)d_queries, m, h->dim,
+		                   (__bf16*)h->d_q_split);
+		HIP_TRY(h, hipGetLastError());
 	}
 
 	for (int attempt = 0;; ++attempt) {
@@ -468,7 +514,9 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
 				hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 				                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
-				                   (const float*)sp.tau, 1.0f - gemm_filter_eps(h->dim), h->d_theta);
+				                   (const float*)sp.tau,
+				                   1.0f - (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)),
+				                   h->d_theta);
 				GemmScanParams gp{};
 				gp.base = (const float*)h->d_base;
 				gp.bnorm = h->d_bnorm;
@@ -506,10 +554,41 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-				                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
+				if (gvb) {
+					GemmBf16Params bp{};
+					bp.base_split = h->d_base_split;
+					bp.bnorm = h->d_bnorm_bf;
+					bp.n_rows = gp.n_rows;
+					bp.n_tiles_sel = gp.n_tiles_sel;
+					bp.tile_stride = gp.tile_stride;
+					bp.tile_run = 1;
+					if (!last && gp.tile_stride >= 8) {
+						// sampled level: runs of 8 consecutive tiles (one 2 MiB page each at d=128)
+						// instead of isolated tiles, same number of tiles
+						bp.tile_run = 8;
+						bp.n_tiles_sel = (gp.n_tiles_sel / 8) * 8;
+						if (bp.n_tiles_sel == 0) {
+							bp.n_tiles_sel = gp.n_tiles_sel;
+							bp.tile_run = 1;
+						}
+					}
+					bp.tiles_per_block = gp.tiles_per_block;
+					bp.n_qtiles = gp.n_qtiles;
+					bp.queries_split = h->d_q_split;
+					bp.theta = gp.theta;
+					bp.m = gp.m;
+					bp.cand_cnt = gp.cand_cnt;
+					bp.cand = gp.cand;
+					bp.cap = gp.cap;
+					hipLaunchKernelGGL(gvb->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+					                   2 * kGemmTB * h->dim * sizeof(float), st, bp);
+					kname = gvb->name;
+				} else {
+					hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+					                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
+					kname = gv->name;
+				}
 				passes = gp.n_qtiles;
-				kname = gv->name;
 				qt_used = kGemmTQ;
 			} else if (gvi && !first) {
 				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
@@ -715,6 +794,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		delete h;
 		return EXPANN_ERR_HIP;
 	}
+	for (const auto& v : kGemmBf16)
+		if (v.d == dim)
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        2 * kGemmTB * dim * (int)sizeof(float)) != hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_bf16_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
 	for (const auto& v : kGemmF32)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -749,6 +837,9 @@ void expann_destroy(expann_index* h) {
 	if (h->d_tau[1]) hipFree(h->d_tau[1]);
 	if (h->d_overflow) hipFree(h->d_overflow);
 	if (h->d_bnorm) hipFree(h->d_bnorm);
+	if (h->d_bnorm_bf) hipFree(h->d_bnorm_bf);
+	if (h->d_base_split) hipFree(h->d_base_split);
+	if (h->d_q_split) hipFree(h->d_q_split);
 	if (h->d_bias_i) hipFree(h->d_bias_i);
 	if (h->d_qself) hipFree(h->d_qself);
 	if (h->d_theta) hipFree(h->d_theta);
@@ -819,6 +910,14 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 	if (h->d_bias_i) {
 		hipFree(h->d_bias_i);
 		h->d_bias_i = nullptr;
+	}
+	if (h->d_bnorm_bf) {
+		hipFree(h->d_bnorm_bf);
+		h->d_bnorm_bf = nullptr;
+	}
+	if (h->d_base_split) {
+		hipFree(h->d_base_split);
+		h->d_base_split = nullptr;
 	}
 	h->d_base = const_cast<void*>(d_rows);
 	h->owns_base = false;

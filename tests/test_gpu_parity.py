@@ -111,23 +111,26 @@ def test_every_query_tile_gives_the_same_answer(gpu, oracle):
     (70000, 128, 300, 100),
     (300, 128, 129, 10),      # fewer rows than one 128-row tile pair
 ])
-def test_gemm_form_scan_bit_exact_vs_oracle(gpu, oracle, n, d, m, k):
-    """scan_kernel=2 forces the MFMA GEMM-form candidate filter (+ exact re-rank in the select
-    kernel): the final ids and distances must still be bit-identical to the oracle."""
+@pytest.mark.parametrize("kernel,kname", [(2, "scan_gemm_f32"), (3, "scan_gemm_bf16x3")])
+def test_gemm_form_scan_bit_exact_vs_oracle(gpu, oracle, n, d, m, k, kernel, kname):
+    """scan_kernel=2/3 force the MFMA GEMM-form candidate filters (fp32-input MFMA, bf16 MFMA
+    with the 3-term split) + exact re-rank in the select kernel: the final ids and distances
+    must still be bit-identical to the oracle."""
     rng = np.random.RandomState(n * 7 + m)
     base = rng.standard_normal((n, d)).astype(np.float32)
     queries = rng.standard_normal((m, d)).astype(np.float32)
     eng = _engine(base)
-    eng.set_option("scan_kernel", 2)
+    eng.set_option("scan_kernel", kernel)
     eng.set_profiling(True)
     _check(oracle, base, queries, k, eng=eng)
     prof = eng.get_profile()
     if n > 1024:
-        assert prof["scan_kernel"].startswith("scan_gemm_f32")
+        assert prof["scan_kernel"].startswith(kname)
     eng.close()
 
 
-def test_gemm_form_scan_near_duplicates_and_ties(gpu, oracle):
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_gemm_form_scan_near_duplicates_and_ties(gpu, oracle, kernel):
     """The expanded form ||b||^2 - 2q.b + ||q||^2 cancels catastrophically for near-duplicate
     vectors (SURVEY 7 'hard parts'); the slack + exact re-rank must keep the result exact."""
     rng = np.random.RandomState(42)
@@ -136,8 +139,15 @@ def test_gemm_form_scan_near_duplicates_and_ties(gpu, oracle):
     base = np.concatenate([uniq, near, uniq[:500]], 0)
     queries = np.concatenate([uniq[:100] + np.float32(1e-5), uniq[100:140]], 0)
     eng = _engine(base)
-    eng.set_option("scan_kernel", 2)
+    eng.set_option("scan_kernel", kernel)
     _check(oracle, base, queries, 10, eng=eng)
+    # wide dynamic range (values from 1e-3 to 1e3 in one vector) stresses the bf16 split
+    wide = (rng.standard_normal((6000, 128)) * 10.0 ** rng.uniform(-3, 3, size=(6000, 128))).astype(np.float32)
+    wq = (rng.standard_normal((128, 128)) * 10.0 ** rng.uniform(-3, 3, size=(128, 128))).astype(np.float32)
+    eng2 = _engine(wide)
+    eng2.set_option("scan_kernel", kernel)
+    _check(oracle, wide, wq, 10, eng=eng2)
+    eng2.close()
     eng.close()
 
 
