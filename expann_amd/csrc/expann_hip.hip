@@ -525,7 +525,8 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				gp.n_tiles_sel = last ? n_tiles
 				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
 				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				gp.n_qtiles = (uint32_t)((m + kGemmTQ - 1) / kGemmTQ);
+				const uint32_t tq_wg = gvb ? kGemmBf16TQ : kGemmTQ;
+				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
 				gp.queries = (const float*)d_queries;
 				gp.theta = h->d_theta;
 				gp.m = (uint32_t)m;
@@ -589,7 +590,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 					kname = gv->name;
 				}
 				passes = gp.n_qtiles;
-				qt_used = kGemmTQ;
+				qt_used = tq_wg;
 			} else if (gvi && !first) {
 				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 				                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,

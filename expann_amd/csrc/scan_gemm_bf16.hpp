@@ -15,9 +15,11 @@
 // the final ids and distances are bit-identical to the direct scan.
 //
 // Layout: base rows and queries are pre-split into [row][hi: d bf16][lo: d bf16] (same 4d bytes
-// per row as fp32).  Workgroup step = 128 queries x 128 rows; 8 waves as 4 (query quarters of
-// 32) x 2 (row halves of 64): a wave owns 2 MFMA tiles sharing one A fragment pair; the A
-// fragments (d/16 k-steps x {hi,lo} x 4 VGPRs) stay in registers.  A lane's k-slice of a part
+// per row as fp32).  Workgroup step = 256 queries x 128 rows -- the kernel is bound by the LDS
+// fill rate of a CU (~25 GB/s per CU by LDS-DMA), so the query tile is as large as the register
+// file allows: 8 waves x 32 queries, each wave against all 128 rows of the tile (4 MFMA tiles
+// sharing one A fragment pair); the A fragments (d/16 k-steps x {hi,lo} x 4 VGPRs) stay in
+// registers.  A lane's k-slice of a part
 // is dims [d/2*h, d/2*(h+1)) (h = lane>>5), 8 dims per MFMA.  LDS staging and the source-side XOR
 // swizzle are those of scan_gemm_f32.hpp.
 #pragma once
@@ -27,6 +29,8 @@
 namespace expann {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kGemmBf16TQ = 256;  // queries per workgroup: 8 waves x 32
 
 __host__ __device__ inline float gemm_bf16_filter_eps(int d) {
 	return (float)(10 * d + 512) * 5.9604644775390625e-08f;
@@ -77,11 +81,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int wr = wave >> 1, wc = wave & 1;  // 4 query quarters of 32 x 2 row halves of 64
+	const int wr = wave;  // each wave: 32 queries x all 128 rows of the tile (4 MFMA tiles)
 	const int h = lane >> 5, r31 = lane & 31;
 	const uint32_t qtile = blockIdx.x % p.n_qtiles;
 	const uint32_t chunk = blockIdx.x / p.n_qtiles;
-	const uint32_t q0 = qtile * kGemmTQ;
+	const uint32_t q0 = qtile * kGemmBf16TQ;
 
 	// query fragments: {hi, lo} x KS k-steps.  k-step s of lane half h covers dims
 	// [8*(h*KS + s), +8) of a part, i.e. 16-byte chunk h*KS + s of the part's 2*D bytes.
@@ -113,37 +117,51 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kGemmTB;
 	};
 
+	// Per-lane byte offset of this thread's 16-byte chunk inside a tile (the same for every
+	// staging instruction: an instruction covers kGemmThreads/CH whole rows, a multiple of 16, so
+	// the swizzle term does not depend on the instruction index).
+	constexpr int ROWS_PER_INSTR = kGemmThreads / CH;
+	static_assert(ROWS_PER_INSTR % (16 * RPB) == 0, "swizzle must be instruction-invariant");
+	const uint32_t lane_row = tid / CH;
+	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
 	auto stage = [&](uint32_t t, int buf) {
 		const uint32_t row0 = tile_row0(t);
+		unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
+		if (row0 + kGemmTB <= p.n_rows) {  // whole tile in range: uniform base + lane offset
+			const unsigned char* tb = (const unsigned char*)p.base_split + (size_t)row0 * ROWB;
 #pragma unroll
-		for (int i = 0; i < kGemmTB * CH / kGemmThreads; ++i) {
-			const int S = i * kGemmThreads + tid;
-			const int r = S / CH, pc = S % CH;
-			const int c = pc ^ ((r / RPB) & SWM);
-			uint32_t grow = row0 + r;
-			if (grow >= p.n_rows)
-				grow = p.n_rows - 1;
-			const unsigned char* src = (const unsigned char*)p.base_split + (size_t)grow * ROWB + c * 16;
-			unsigned char* dst = smem + buf * TILE_BYTES + (i * kGemmThreads + wave * 64) * 16;
-			__builtin_amdgcn_global_load_lds(
-			    (const __attribute__((address_space(1))) void*)src,
-			    (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+			for (int i = 0; i < kGemmTB * CH / kGemmThreads; ++i)
+				__builtin_amdgcn_global_load_lds(
+				    (const __attribute__((address_space(1))) void*)(tb + lane_off +
+				                                                    (uint32_t)i * ROWS_PER_INSTR * ROWB),
+				    (__attribute__((address_space(3))) void*)(dst0 + i * kGemmThreads * 16), 16, 0, 0);
+		} else {  // ragged last tile: clamp the row
+#pragma unroll
+			for (int i = 0; i < kGemmTB * CH / kGemmThreads; ++i) {
+				uint32_t grow = row0 + i * ROWS_PER_INSTR + lane_row;
+				if (grow >= p.n_rows)
+					grow = p.n_rows - 1;
+				const unsigned char* src = (const unsigned char*)p.base_split + (size_t)grow * ROWB +
+				                           (lane_off - lane_row * ROWB);
+				__builtin_amdgcn_global_load_lds(
+				    (const __attribute__((address_space(1))) void*)src,
+				    (__attribute__((address_space(3))) void*)(dst0 + i * kGemmThreads * 16), 16, 0, 0);
+			}
 		}
 	};
 
-	auto epilogue = [&](const f32x16& acc0, const f32x16& acc1, uint32_t row0) {
+	auto epilogue = [&](const f32x16 (&accs)[4], uint32_t row0) {
 #pragma unroll
-		for (int tc = 0; tc < 2; ++tc) {
-			const uint32_t brow = row0 + wc * 64 + tc * 32 + r31;
+		for (int tc = 0; tc < 4; ++tc) {
+			const uint32_t brow = row0 + tc * 32 + r31;
 			const float bn = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
-			const f32x16& acc = tc ? acc1 : acc0;
 #pragma unroll
 			for (int r4 = 0; r4 < 16; r4 += 4) {
 				float tv[4];
 				bool any = false;
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
-					tv[e] = __builtin_fmaf(-2.0f, acc[r4 + e], bn);
+					tv[e] = __builtin_fmaf(-2.0f, accs[tc][r4 + e], bn);
 					any |= tv[e] <= th[r4 + e];
 				}
 				if (__builtin_amdgcn_ballot_w64(any) != 0) {
@@ -166,8 +184,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		stage(t0, 0);
 	__syncthreads();
 
-	const bool deferred = wave >= 4;  // SIMD partners (w, w+4) alternate MFMA and epilogue phases
-	f32x16 acc0, acc1;
+	// SIMD partners (w, w+4) alternate MFMA and epilogue phases: waves 4-7 test the accumulators
+	// of tile t at the start of step t+1, under their partner's MFMAs
+	const bool deferred = wave >= 4;
+	f32x16 acc[4];
 	uint32_t prev_row0 = 0;
 	bool have_prev = false;
 
@@ -176,43 +196,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		if (t + 1 < t1)
 			stage(t + 1, buf ^ 1);
 		if (deferred && have_prev)
-			epilogue(acc0, acc1, prev_row0);
+			epilogue(acc, prev_row0);
 #pragma unroll
-		for (int e = 0; e < 16; ++e) {
-			acc0[e] = 0.0f;
-			acc1[e] = 0.0f;
-		}
+		for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+			for (int e = 0; e < 16; ++e)
+				acc[tc][e] = 0.0f;
 		const unsigned char* bt = smem + buf * TILE_BYTES;
-		const int rb0 = wc * 64 + r31, rb1 = rb0 + 32;
-		auto frag = [&](int rb, int part, int s) -> bf16x8 {
-			const int c = (part * (CH / 2) + h * KS + s) ^ ((rb / RPB) & SWM);
-			return *reinterpret_cast<const bf16x8*>(bt + rb * ROWB + c * 16);
+		const int sw = (r31 / RPB) & SWM;  // (tc*32 + r31) / RPB has the same low bits
+		auto frag = [&](int tc, int part, int s) -> bf16x8 {
+			const int c = (part * (CH / 2) + h * KS + s) ^ sw;
+			return *reinterpret_cast<const bf16x8*>(bt + (tc * 32 + r31) * ROWB + c * 16);
 		};
-		bf16x8 bh0 = frag(rb0, 0, 0), bl0 = frag(rb0, 1, 0), bh1 = frag(rb1, 0, 0), bl1 = frag(rb1, 1, 0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
-			bf16x8 nbh0 = bh0, nbl0 = bl0, nbh1 = bh1, nbl1 = bl1;
-			if (s + 1 < KS) {
-				nbh0 = frag(rb0, 0, s + 1);
-				nbl0 = frag(rb0, 1, s + 1);
-				nbh1 = frag(rb1, 0, s + 1);
-				nbl1 = frag(rb1, 1, s + 1);
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {  // two column tiles at a time (register budget)
+				const int ta = 2 * half, tb = ta + 1;
+				const bf16x8 bha = frag(ta, 0, s), bla = frag(ta, 1, s);
+				const bf16x8 bhb = frag(tb, 0, s), blb = frag(tb, 1, s);
+				// small cross terms first, the dominant hi.hi product last
+				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bha, acc[ta], 0, 0, 0);
+				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bhb, acc[tb], 0, 0, 0);
+				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bla, acc[ta], 0, 0, 0);
+				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], blb, acc[tb], 0, 0, 0);
+				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bha, acc[ta], 0, 0, 0);
+				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bhb, acc[tb], 0, 0, 0);
 			}
-			// small cross terms first, the dominant hi.hi product last
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bh0, acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bh1, acc1, 0, 0, 0);
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bl0, acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bl1, acc1, 0, 0, 0);
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bh0, acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bh1, acc1, 0, 0, 0);
-			bh0 = nbh0;
-			bl0 = nbl0;
-			bh1 = nbh1;
-			bl1 = nbl1;
 		}
 		const uint32_t row0 = tile_row0(t);
 		if (!deferred) {
-			epilogue(acc0, acc1, row0);
+			epilogue(acc, row0);
 		} else {
 			prev_row0 = row0;
 			have_prev = true;
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		__syncthreads();
 	}
 	if (deferred && have_prev)
-		epilogue(acc0, acc1, prev_row0);
+		epilogue(acc, prev_row0);
 }
 
 }  // namespace expann
