@@ -42,6 +42,9 @@ def parse():
                          "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric)")
     ap.add_argument("--query-tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--scan-kernel", type=int, default=0,
+                    help="0 auto, 1 direct, 2 GEMM form fp32/int8 MFMA, 3 GEMM form bf16x3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="rough budget of the CPU baseline leg")
     a = ap.parse_args()
@@ -178,6 +181,10 @@ def main():
     eng.set_base_device(base.data_ptr(), hi - lo, lo)
     if a.query_tile:
         eng.set_option("query_tile", a.query_tile)
+    if a.scan_kernel:
+        eng.set_option("scan_kernel", a.scan_kernel)
+    if a.debug:
+        eng.set_option("debug", a.debug)
     ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
     dists = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
     out_ids = torch.empty_like(ids)

@@ -67,6 +67,7 @@ struct expann_index {
 	uint32_t* h_flags = nullptr;     // pinned [4]
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
+	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
 	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
 	void* d_q_split = nullptr;       // [m][2][dim] bf16
 	size_t q_split_bytes = 0;
@@ -79,6 +80,7 @@ struct expann_index {
 	size_t io_q_bytes = 0, io_out = 0;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
+	long opt_debug = 0;
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
@@ -332,6 +334,10 @@ int ensure_bnorm(expann_index* h, const GemmVariant* gv, bool bf16, hipStream_t 
 		const float eps = bf16 ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim);
 		hipLaunchKernelGGL(gv->norms, dim3(blocks), dim3(kBlock), 0, st, (const float*)h->d_base,
 		                   (uint32_t)h->n, 1.0f - eps, dst);
+		if (!h->d_bnmax)
+			HIP_TRY(h, hipMalloc(&h->d_bnmax, 2 * sizeof(float)));
+		hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)dst, h->n,
+		                   h->d_bnmax + (bf16 ? 1 : 0));
 		HIP_TRY(h, hipGetLastError());
 	}
 	if (bf16 && !h->d_base_split) {
@@ -581,6 +587,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 					bp.cand_cnt = gp.cand_cnt;
 					bp.cand = gp.cand;
 					bp.cap = gp.cap;
+					bp.debug = (uint32_t)h->opt_debug;
 					hipLaunchKernelGGL(gvb->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
 					                   2 * kGemmTB * h->dim * sizeof(float), st, bp);
 					kname = gvb->name;
@@ -670,10 +677,12 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
 			sel.dim = (uint32_t)h->dim;
 			sel.metric_ip = ip ? 1u : 0u;
+			sel.prune_eps = use_gemm ? (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)) : 0.0f;
+			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvb ? 1 : 0) : nullptr;
 			sel.overflow = h->d_overflow;
 			sel.total_cand = last ? h->d_total : nullptr;
 			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
-			                   sizeof(uint64_t) * cap, st, sel);
+			                   sizeof(uint64_t) * cap + 16, st, sel);
 			HIP_TRY(h, hipGetLastError());
 		}
 		// overflow check (the only host sync of a search)
@@ -789,7 +798,7 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	// the select kernel sorts up to kMaxCap 8-byte keys in LDS (128 KiB of the CU's 160 KiB)
 	if (hipFuncSetAttribute((const void*)select_topk_kernel,
 	                        hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        (int)(sizeof(uint64_t) * kMaxCap)) != hipSuccess) {
+	                        (int)(sizeof(uint64_t) * kMaxCap + 16)) != hipSuccess) {
 		g_create_error = "hipFuncSetAttribute(select_topk_kernel) failed";
 		hipStreamDestroy(h->stream);
 		delete h;
@@ -839,6 +848,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_overflow) hipFree(h->d_overflow);
 	if (h->d_bnorm) hipFree(h->d_bnorm);
 	if (h->d_bnorm_bf) hipFree(h->d_bnorm_bf);
+	if (h->d_bnmax) hipFree(h->d_bnmax);
 	if (h->d_base_split) hipFree(h->d_base_split);
 	if (h->d_q_split) hipFree(h->d_q_split);
 	if (h->d_bias_i) hipFree(h->d_bias_i);
@@ -1458,6 +1468,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_query_tile = value;
 	else if (!std::strcmp(name, "cand_capacity"))
 		h->opt_cand_capacity = value;
+	else if (!std::strcmp(name, "debug"))
+		h->opt_debug = value;
 	else if (!std::strcmp(name, "scan_kernel"))
 		h->opt_scan_kernel = value;
 	else if (!std::strcmp(name, "sample_ratio"))

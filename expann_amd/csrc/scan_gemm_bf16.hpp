@@ -65,6 +65,7 @@ struct GemmBf16Params {
 	uint32_t* cand_cnt;
 	uint64_t* cand;
 	uint32_t cap;
+	uint32_t debug;  // timing experiments only: 1 = no epilogue, 2 = no staging, 4 = no MFMA
 };
 
 template <int D>
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 	constexpr int KS = D / 16;       // MFMA k-steps per part
 	constexpr int TILE_BYTES = kGemmTB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
-	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
+	// XOR mask: stays inside one part (hi or lo) of the row; 16 values at d=128 (conflict-free
+	// ds_read_b128), 8 at d=64 (2-way)
+	constexpr int SWM = (CH / 2 < 16 ? CH / 2 : 16) - 1;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const int tid = threadIdx.x;
@@ -108,6 +111,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 		th[reg] = qi < p.m ? p.theta[qi] : -__builtin_inff();
 	}
+
+	// LDS byte offset (within a tile) of this lane's 16-byte chunk of k-step s, column tile 0,
+	// hi part: row r31, chunk (h*KS + s) ^ swizzle(r31).  Column tile tc adds tc*32 rows (the
+	// swizzle only looks at row bits below 32*RPB... i.e. is unchanged), the lo part adds CH/2
+	// chunks (the XOR never touches that bit: SWM < CH/2).
+	static_assert(SWM < CH / 2 && (32 / RPB) % (SWM + 1) == 0, "swizzle layout");
+	uint32_t aoff[KS];
+#pragma unroll
+	for (int s = 0; s < KS; ++s)
+		aoff[s] = r31 * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
 
 	const uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
@@ -150,11 +163,18 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 		}
 	};
 
-	auto epilogue = [&](const f32x16 (&accs)[4], uint32_t row0) {
+	auto load_bn = [&](float (&bnv)[4], uint32_t row0) {
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc) {
 			const uint32_t brow = row0 + tc * 32 + r31;
-			const float bn = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
+			bnv[tc] = brow < p.n_rows ? p.bnorm[brow] : __builtin_inff();
+		}
+	};
+	auto epilogue = [&](const f32x16 (&accs)[4], uint32_t row0, const float (&bnv)[4]) {
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc) {
+			const uint32_t brow = row0 + tc * 32 + r31;
+			const float bn = bnv[tc];
 #pragma unroll
 			for (int r4 = 0; r4 < 16; r4 += 4) {
 				float tv[4];
@@ -165,11 +185,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 					any |= tv[e] <= th[r4 + e];
 				}
 				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+					// rare path: keep its address arithmetic inside the branch (hoisted out of the
+					// tile loop it would pin ~64 VGPRs of per-query pointers)
+					uint32_t qrow0 = q0 + wr * 32 + 4 * h;
+					asm volatile("" : "+v"(qrow0));
 #pragma unroll
 					for (int e = 0; e < 4; ++e) {
 						const int reg = r4 + e;
 						if (tv[e] <= th[reg]) {
-							const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+							const uint32_t qi = qrow0 + (reg & 3) + 8 * (reg >> 2);
 							const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
 							if (slot < p.cap)
 								p.cand[(size_t)qi * p.cap + slot] = make_key(tv[e], brow);
@@ -191,50 +215,81 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf1
 	uint32_t prev_row0 = 0;
 	bool have_prev = false;
 
+	// Ordering against the LDS-DMA queue: vector-memory operations retire in issue order, so a
+	// load or returning atomic issued AFTER the 16 staging instructions cannot complete before the
+	// whole next tile has landed.  The deferred waves therefore run their epilogue (norm loads,
+	// rare atomics) BEFORE they issue their share of the staging; the other waves fetch the row
+	// norms of the current tile before staging and keep them in 4 VGPRs until their epilogue.
+	float bnv[4];
 	int buf = 0;
 	for (uint32_t t = t0; t < t1; ++t, buf ^= 1) {
-		if (t + 1 < t1)
+		if (deferred) {
+			if (have_prev && !(p.debug & 1)) {
+				load_bn(bnv, prev_row0);
+				epilogue(acc, prev_row0, bnv);
+			}
+		} else {
+			load_bn(bnv, tile_row0(t));
+		}
+		if (t + 1 < t1 && !(p.debug & 2))
 			stage(t + 1, buf ^ 1);
-		if (deferred && have_prev)
-			epilogue(acc, prev_row0);
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 #pragma unroll
 			for (int e = 0; e < 16; ++e)
 				acc[tc][e] = 0.0f;
-		const unsigned char* bt = smem + buf * TILE_BYTES;
-		const int sw = (r31 / RPB) & SWM;  // (tc*32 + r31) / RPB has the same low bits
+		// fragment of column tile tc, part (0 = hi, 1 = lo), k-step s: the swizzled chunk index
+		// splits into a per-lane term (aoff[s], hoisted) and compile-time offsets
+		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int tc, int part, int s) -> bf16x8 {
-			const int c = (part * (CH / 2) + h * KS + s) ^ sw;
-			return *reinterpret_cast<const bf16x8*>(bt + (tc * 32 + r31) * ROWB + c * 16);
+			return *reinterpret_cast<const bf16x8*>(smem + (boff + aoff[s]) + tc * 32 * ROWB +
+			                                        part * (CH / 2) * 16);
 		};
+		// 2*KS half-steps (k-step s, column-tile pair `half`); the fragments of half-step i+1 are
+		// read from LDS while the six MFMAs of half-step i run
+		bf16x8 bha = frag(0, 0, 0), bla = frag(0, 1, 0), bhb = frag(1, 0, 0), blb = frag(1, 1, 0);
+		if (!(p.debug & 4))
 #pragma unroll
-		for (int s = 0; s < KS; ++s) {
-#pragma unroll
-			for (int half = 0; half < 2; ++half) {  // two column tiles at a time (register budget)
-				const int ta = 2 * half, tb = ta + 1;
-				const bf16x8 bha = frag(ta, 0, s), bla = frag(ta, 1, s);
-				const bf16x8 bhb = frag(tb, 0, s), blb = frag(tb, 1, s);
-				// small cross terms first, the dominant hi.hi product last
-				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bha, acc[ta], 0, 0, 0);
-				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bhb, acc[tb], 0, 0, 0);
-				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bla, acc[ta], 0, 0, 0);
-				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], blb, acc[tb], 0, 0, 0);
-				acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bha, acc[ta], 0, 0, 0);
-				acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bhb, acc[tb], 0, 0, 0);
+		for (int hs = 0; hs < 2 * KS; ++hs) {
+			const int s = hs >> 1, ta = 2 * (hs & 1), tb = ta + 1;
+			bf16x8 nha = bha, nla = bla, nhb = bhb, nlb = blb;
+			if (hs + 1 < 2 * KS) {
+				const int ns = (hs + 1) >> 1, nta = 2 * ((hs + 1) & 1);
+				nha = frag(nta, 0, ns);
+				nla = frag(nta, 1, ns);
+				nhb = frag(nta + 1, 0, ns);
+				nlb = frag(nta + 1, 1, ns);
 			}
+			// small cross terms first, the dominant hi.hi product last
+			acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bha, acc[ta], 0, 0, 0);
+			acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bhb, acc[tb], 0, 0, 0);
+			acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bla, acc[ta], 0, 0, 0);
+			acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], blb, acc[tb], 0, 0, 0);
+			acc[ta] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bha, acc[ta], 0, 0, 0);
+			acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bhb, acc[tb], 0, 0, 0);
+			bha = nha;
+			bla = nla;
+			bhb = nhb;
+			blb = nlb;
+			// pin the issue order: the 4 fragment reads of the next half-step first, then the
+			// 6 MFMAs of this one (hipcc otherwise sinks the reads to just before their use)
+			__builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 		}
 		const uint32_t row0 = tile_row0(t);
 		if (!deferred) {
-			epilogue(acc, row0);
+			if (!(p.debug & 1))
+				epilogue(acc, row0, bnv);
 		} else {
 			prev_row0 = row0;
 			have_prev = true;
 		}
 		__syncthreads();
 	}
-	if (deferred && have_prev)
-		epilogue(acc, prev_row0);
+	if (deferred && have_prev) {
+		load_bn(bnv, prev_row0);
+		epilogue(acc, prev_row0, bnv);
+	}
 }
 
 }  // namespace expann

@@ -24,6 +24,13 @@ struct SelectParams {
 	const float* rerank_queries;  // [m][dim]
 	uint32_t dim;
 	uint32_t metric_ip;
+	// rerank pruning (L2 GEMM forms): the approximate key A = bn(1-eps) - 2 q.b satisfies
+	//   A + qn(1-eps/2)  <=  reference-order score  <=  A + qn(1+eps/2) + 1.5 eps bn
+	// (the slack eps is at least twice the worst-case evaluation error, scan_gemm_*.hpp), so a
+	// candidate whose A exceeds the k-th smallest A by more than eps*(qn + 1.5*bn_max) cannot be
+	// among the k best and need not be re-scored.  prune_eps == 0 disables it.
+	float prune_eps;
+	const float* bn_max;      // [1] max over rows of ||b||^2 (1-eps)
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
 	unsigned long long* total_cand;  // [1] sum of counts (statistics) or nullptr
 };
@@ -46,18 +53,63 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	while (n2 < c)
 		n2 <<= 1;
 	const uint64_t* src = p.cand + (size_t)qi * p.cap;
+	for (uint32_t i = tid; i < n2; i += kBlock)
+		keys[i] = i < c ? src[i] : kSentinelKey;
+	__syncthreads();
+	auto bitonic = [&](uint32_t len) {
+		for (uint32_t size = 2; size <= len; size <<= 1) {
+			for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+				for (uint32_t i = tid; i < (len >> 1); i += kBlock) {
+					const uint32_t lo = 2 * i - (i & (stride - 1));
+					const uint32_t hi = lo + stride;
+					const bool up = ((lo & size) == 0);
+					const uint64_t a = keys[lo], b = keys[hi];
+					if ((a > b) == up) {
+						keys[lo] = b;
+						keys[hi] = a;
+					}
+				}
+				__syncthreads();
+			}
+		}
+	};
 	if (p.rerank_base) {
-		// 16 lanes per candidate row, lane l owns dims l, l+16, ... in increasing order and
-		// the partial sums meet in the _mm512_reduce_add_ps tree: the scores written here are
-		// bit-identical to scan_filter_f32_kernel's (src/distance.h:136-147 / :181-190).
-		const uint32_t l = tid & 15, grp = tid >> 4;  // 16 candidates per pass
+		const uint32_t l = tid & 15, grp = tid >> 4;  // 16 lanes per candidate row
 		const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
-		for (uint32_t i0 = 0; i0 < n2; i0 += kBlock / 16) {
+		uint32_t n_rescore = c;
+		if (p.prune_eps > 0.0f && !p.metric_ip && c > p.k) {
+			// order by the approximate key, keep what can still reach the k best
+			bitonic(n2);
+			float qn = 0.0f;
+			for (uint32_t t = 0; t < p.dim / 16; ++t)
+				qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
+			qn = reduce16_ref_order(qn);
+			const float cutoff = key_score(keys[p.k - 1]) + p.prune_eps * (qn + 1.5f * p.bn_max[0]);
+			uint32_t cnt = 0;
+			for (uint32_t i = tid; i < c; i += kBlock)
+				cnt += key_score(keys[i]) <= cutoff ? 1u : 0u;
+			// (counter lives behind the keys in the dynamic LDS region: a static __shared__ object
+			// would shift the 16-byte alignment of the dynamic base)
+			uint32_t* s_cnt = reinterpret_cast<uint32_t*>(keys + p.cap);
+			if (tid == 0)
+				*s_cnt = 0;
+			__syncthreads();
+			if (cnt)
+				atomicAdd(s_cnt, cnt);
+			__syncthreads();
+			n_rescore = *s_cnt;  // keys are sorted: exactly the first *s_cnt qualify
+			__syncthreads();
+		}
+		uint32_t n2r = 2;
+		while (n2r < n_rescore)
+			n2r <<= 1;
+		// exact re-score: lane l owns dims l, l+16, ... in increasing order and the partial sums
+		// meet in the _mm512_reduce_add_ps tree: bit-identical to scan_filter_f32_kernel's scores
+		// (src/distance.h:136-147 / :181-190)
+		for (uint32_t i0 = 0; i0 < n2r; i0 += kBlock / 16) {
 			const uint32_t i = i0 + grp;
-			uint64_t key = kSentinelKey;
-			if (i < c)
-				key = src[i];
-			const uint32_t row = (i < c) ? key_idx(key) : 0u;
+			const bool live = i < n_rescore;
+			const uint32_t row = live ? key_idx(keys[i]) : 0u;
 			const float* r = p.rerank_base + (size_t)row * p.dim + l;
 			float acc = 0.0f;
 			for (uint32_t t = 0; t < p.dim / 16; ++t) {
@@ -69,29 +121,14 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 				}
 			}
 			acc = reduce16_ref_order(acc);
-			if (l == 0 && i < n2)
-				keys[i] = (i < c) ? make_key(p.metric_ip ? -acc : acc, row) : kSentinelKey;
+			__syncthreads();  // every key of this pass has been read before any is overwritten
+			if (l == 0 && i < n2r)
+				keys[i] = live ? make_key(p.metric_ip ? -acc : acc, row) : kSentinelKey;
 		}
-	} else {
-		for (uint32_t i = tid; i < n2; i += kBlock)
-			keys[i] = i < c ? src[i] : kSentinelKey;
+		__syncthreads();
+		n2 = n2r;
 	}
-	__syncthreads();
-	for (uint32_t size = 2; size <= n2; size <<= 1) {
-		for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-			for (uint32_t i = tid; i < (n2 >> 1); i += kBlock) {
-				const uint32_t lo = 2 * i - (i & (stride - 1));
-				const uint32_t hi = lo + stride;
-				const bool up = ((lo & size) == 0);
-				const uint64_t a = keys[lo], b = keys[hi];
-				if ((a > b) == up) {
-					keys[lo] = b;
-					keys[hi] = a;
-				}
-			}
-			__syncthreads();
-		}
-	}
+	bitonic(n2);
 	for (uint32_t i = tid; i < p.k; i += kBlock) {
 		const uint64_t key = i < n2 ? keys[i] : kSentinelKey;
 		const bool ok = key != kSentinelKey;
@@ -104,6 +141,26 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 		const uint64_t key = (p.k - 1 < n2) ? keys[p.k - 1] : kSentinelKey;
 		p.tau_out[qi] = key != kSentinelKey ? key_score(key)
 		                                    : (p.tau_prev ? p.tau_prev[qi] : __builtin_inff());
+	}
+}
+
+// max of a float array (single workgroup; used once per build for the rerank pruning bound)
+__global__ __launch_bounds__(1024) void max_f32_kernel(const float* in, size_t n, float* out) {
+	__shared__ float red[16];
+	float m = -__builtin_inff();
+	for (size_t i = threadIdx.x; i < n; i += 1024)
+		m = in[i] > m ? in[i] : m;
+	for (int off = 32; off > 0; off >>= 1) {
+		const float o = __shfl_xor(m, off);
+		m = o > m ? o : m;
+	}
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 16; ++w)
+			m = red[w] > m ? red[w] : m;
+		out[0] = m;
 	}
 }
 
