@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (155 measured)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 MFMA_I8_PEAK_TOPS = 5033.0     # int8 MFMA = 2x the bf16 rate per clock (~2.5 PF dense bf16):
                                # 2048 ops/clk/SIMD x 1024 SIMDs x 2.4 GHz
 
@@ -255,6 +256,17 @@ def main():
             tops = ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS,
                         "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
+        elif prof["scan_kernel"].startswith("scan_gemm_bf16x3"):
+            # fp32 products evaluated exactly enough on the bf16 cores as 3 bf16 MFMA products
+            # (hi*hi + hi*lo + lo*hi): executed flops = 3 x the algorithmic 2*N*d*m
+            alg = 2.0 * n_local * a.d * a.m
+            tf_alg = alg / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": round(3 * tf_alg, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(3 * tf_alg / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "mfma_dtype": "bf16 (3-term split of fp32 operands, results exact after re-rank)",
+                        "mfma_products_per_fp32_product": 3,
+                        "algorithmic_TFLOPs": round(tf_alg, 1),
+                        "algorithmic_vs_fp32_mfma_peak": round(tf_alg / MFMA_F32_PEAK_TFLOPS, 3)}
         elif prof["scan_kernel"].startswith("scan_gemm"):
             # GEMM-form filter on the matrix cores: algorithmic flops = 2*N*d*m
             flops = 2.0 * n_local * a.d * a.m

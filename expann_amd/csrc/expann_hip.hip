@@ -312,8 +312,8 @@ struct GemmBf16Variant {
 	GemmBf16Fn scan;
 	const char* name;
 };
-const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16_kernel<64>, "scan_gemm_bf16x3<64>"},
-                                     {128, scan_gemm_bf16_kernel<128>, "scan_gemm_bf16x3<128>"}};
+const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16x3_kernel<64>, "scan_gemm_bf16x3<64>"},
+                                     {128, scan_gemm_bf16x3_kernel<128>, "scan_gemm_bf16x3<128>"}};
 
 const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
@@ -808,7 +808,7 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
 			                        2 * kGemmTB * dim * (int)sizeof(float)) != hipSuccess) {
-				g_create_error = "hipFuncSetAttribute(scan_gemm_bf16_kernel) failed";
+				g_create_error = "hipFuncSetAttribute(scan_gemm_bf16x3_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
 				return EXPANN_ERR_HIP;

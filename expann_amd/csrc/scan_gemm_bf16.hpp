@@ -69,7 +69,7 @@ struct GemmBf16Params {
 };
 
 template <int D>
-__global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16_kernel(GemmBf16Params p) {
+__global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_bf16x3_kernel(GemmBf16Params p) {
 	static_assert(D == 128 || D == 64, "built for d = 64, 128");
 	constexpr int ROWB = D * 4;      // bytes per split row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row (hi: [0,CH/2), lo: [CH/2,CH))
