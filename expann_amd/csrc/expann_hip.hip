@@ -61,6 +61,7 @@ struct expann_index {
 	size_t cand_elems = 0;
 	uint32_t* d_cnt = nullptr;       // [m] + overflow word + pad
 	float* d_tau[2] = {nullptr, nullptr};
+	uint32_t* d_tau_row[2] = {nullptr, nullptr};
 	size_t m_alloc = 0;
 	uint32_t* d_overflow = nullptr;  // [4]: overflow count
 	unsigned long long* d_total = nullptr;
@@ -273,6 +274,11 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		HIP_TRY(h, hipMalloc(&h->d_cnt, sizeof(uint32_t) * m));
 		HIP_TRY(h, hipMalloc(&h->d_tau[0], sizeof(float) * m));
 		HIP_TRY(h, hipMalloc(&h->d_tau[1], sizeof(float) * m));
+		for (int i = 0; i < 2; ++i) {
+			if (h->d_tau_row[i]) hipFree(h->d_tau_row[i]);
+			h->d_tau_row[i] = nullptr;
+			HIP_TRY(h, hipMalloc(&h->d_tau_row[i], sizeof(uint32_t) * m));
+		}
 		h->m_alloc = m;
 	}
 	const size_t need = m * (size_t)cap;
@@ -443,8 +449,10 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "k too large for the candidate buffers (k <= " +
 		                                           std::to_string(kMaxCap / 2) + ")");
 	const int cus = num_cus(h->device);
-	const GemmVariant* gv = pick_gemm(h, m);
-	const GemmI8Variant* gvi = pick_gemm_i8(h, m);
+	bool force_direct = false;  // set when a GEMM-form filter overflowed: massive near-ties
+restart_direct:
+	const GemmVariant* gv = force_direct ? nullptr : pick_gemm(h, m);
+	const GemmI8Variant* gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
 	if (h->opt_scan_kernel == 2 && !gv && !gvi)
 		return h->fail(EXPANN_ERR_UNSUPPORTED,
 		               "GEMM-form scan: f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
@@ -500,6 +508,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			sp.queries = d_queries;
 			sp.m = (uint32_t)m;
 			sp.tau = first ? nullptr : h->d_tau[(li + 1) & 1];
+			sp.tau_row = first ? nullptr : h->d_tau_row[(li + 1) & 1];
 			sp.cand_cnt = h->d_cnt;
 			sp.cand = h->d_cand;
 			sp.cap = cap;
@@ -673,6 +682,8 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			sel.out_dists = last ? d_dists : nullptr;
 			sel.tau_out = last ? nullptr : h->d_tau[li & 1];
 			sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
+			sel.tau_row_out = last ? nullptr : h->d_tau_row[li & 1];
+			sel.tau_row_prev = first ? nullptr : h->d_tau_row[(li + 1) & 1];
 			sel.rerank_base = use_gemm ? (const float*)h->d_base : nullptr;
 			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
 			sel.dim = (uint32_t)h->dim;
@@ -703,6 +714,11 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 			return EXPANN_OK;
 		// some candidate list overflowed: retry with 4x the capacity
 		h->prof.retries++;
+		if ((cap >= kMaxCap || attempt >= 3) && (gv || gvi) && h->opt_scan_kernel == 0) {
+			// the GEMM forms cannot break exact ties by row number; the direct scan can
+			force_direct = true;
+			goto restart_direct;
+		}
 		if (cap >= kMaxCap || attempt >= 3)
 			return h->fail(EXPANN_ERR_OVERFLOW,
 			               "candidate lists overflowed (" + std::to_string(h->h_flags[0]) +
@@ -845,6 +861,8 @@ void expann_destroy(expann_index* h) {
 	if (h->d_cnt) hipFree(h->d_cnt);
 	if (h->d_tau[0]) hipFree(h->d_tau[0]);
 	if (h->d_tau[1]) hipFree(h->d_tau[1]);
+	if (h->d_tau_row[0]) hipFree(h->d_tau_row[0]);
+	if (h->d_tau_row[1]) hipFree(h->d_tau_row[1]);
 	if (h->d_overflow) hipFree(h->d_overflow);
 	if (h->d_bnorm) hipFree(h->d_bnorm);
 	if (h->d_bnorm_bf) hipFree(h->d_bnorm_bf);

@@ -31,6 +31,7 @@ struct ScanParams {
 	const void* queries;      // [m][D]
 	uint32_t m;
 	const float* tau;         // [m] thresholds, or nullptr: keep everything (level 0)
+	const uint32_t* tau_row;  // [m] row of the threshold key: (score, row) <= (tau, tau_row) passes
 	uint32_t* cand_cnt;       // [m]
 	uint64_t* cand;           // [m][cap] keys (common.hpp: make_key)
 	uint32_t cap;
@@ -142,7 +143,11 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 		} else if (any) {
 #pragma unroll
 			for (int j = 0; j < TQ; ++j) {
-				if (l == 0 && rvalid && q0 + j < p.m && s[j] <= tau[j]) {
+				// exact lexicographic key test (only evaluated on the rare path): ties with the
+				// threshold score pass only up to the threshold's row, which bounds the survivors
+				// even when many rows are identical
+				if (l == 0 && rvalid && q0 + j < p.m &&
+				    (s[j] < tau[j] || (s[j] == tau[j] && row <= p.tau_row[q0 + j]))) {
 					const uint32_t slot = atomicAdd(&p.cand_cnt[q0 + j], 1u);
 					if (slot < p.cap)
 						p.cand[(size_t)(q0 + j) * p.cap + slot] = make_key(s[j], row);

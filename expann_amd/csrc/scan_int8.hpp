@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 		} else if (any) {
 #pragma unroll
 			for (int j = 0; j < TQ; ++j) {
-				if (l == 0 && rvalid && q0 + j < p.m && s[j] <= tau[j]) {
+				if (l == 0 && rvalid && q0 + j < p.m &&
+				    (s[j] < tau[j] || (s[j] == tau[j] && row <= p.tau_row[q0 + j]))) {
 					const uint32_t slot = atomicAdd(&p.cand_cnt[q0 + j], 1u);
 					if (slot < p.cap)
 						p.cand[(size_t)(q0 + j) * p.cap + slot] = make_key(s[j], row);

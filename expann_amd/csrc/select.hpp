@@ -18,6 +18,8 @@ struct SelectParams {
 	float* out_dists;         // [m][k] or nullptr
 	float* tau_out;           // [m] k-th smallest score, or nullptr
 	const float* tau_prev;    // [m] carried forward when fewer than k keys (nullptr: +inf)
+	uint32_t* tau_row_out;    // [m] row of the k-th smallest key (UINT32_MAX when carried) or nullptr
+	const uint32_t* tau_row_prev;
 	// re-rank (GEMM-form scan): when rerank_base != nullptr the keys hold only a row number
 	// (low 32 bits); the exact reference-order score is recomputed here before the sort
 	const float* rerank_base;     // [n][dim]
@@ -141,6 +143,10 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 		const uint64_t key = (p.k - 1 < n2) ? keys[p.k - 1] : kSentinelKey;
 		p.tau_out[qi] = key != kSentinelKey ? key_score(key)
 		                                    : (p.tau_prev ? p.tau_prev[qi] : __builtin_inff());
+		if (p.tau_row_out)
+			p.tau_row_out[qi] = key != kSentinelKey
+			                        ? key_idx(key)
+			                        : (p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu);
 	}
 }
 

@@ -92,6 +92,21 @@ def test_duplicate_rows_tie_break_by_lower_id(gpu, oracle):
     assert np.array_equal(ids2[0], np.arange(10, dtype=np.uint64))
 
 
+@pytest.mark.parametrize("m", [3, 130])
+def test_massive_exact_ties_do_not_overflow(gpu, oracle, m):
+    """40 000 identical rows (more than any candidate buffer holds) plus a few distinct ones: the
+    threshold test is lexicographic on (score, row), so ties pass only up to the threshold's row;
+    the GEMM forms (m = 130) cannot break exact ties and fall back to the direct scan."""
+    rng = np.random.RandomState(55)
+    one = rng.standard_normal((1, 128)).astype(np.float32)
+    base = np.concatenate([rng.standard_normal((500, 128)).astype(np.float32),
+                           np.repeat(one, 40000, 0),
+                           rng.standard_normal((700, 128)).astype(np.float32)], 0)
+    queries = np.concatenate([one + np.float32(0.01), rng.standard_normal((m - 1, 128)).astype(np.float32)], 0)
+    ids, dists = _check(oracle, base, queries, 10)
+    assert np.array_equal(ids[0], np.arange(500, 510, dtype=np.uint64))
+
+
 def test_every_query_tile_gives_the_same_answer(gpu, oracle):
     rng = np.random.RandomState(21)
     base = rng.standard_normal((30000, 128)).astype(np.float32)
