@@ -22,6 +22,7 @@
 #include <string>
 
 #include "expann/basic_bench.h"
+#include "expann/dataset_io.h"
 #include "expann/gpu_brute_force_engine.h"
 
 // flat JSON object of string / number values -> map<string,string>
@@ -79,29 +80,48 @@ int main(int argc, char** argv) {
 		std::exit(2);
 	};
 	const std::string dataset = get("dataset", "Synthetic");
-	if (dataset != "Synthetic") {
-		std::fprintf(stderr, "dataset %s needs *.fvecs files that are not shipped; only "
-		                     "\"Synthetic\" is wired in this driver\n", dataset.c_str());
-		return 2;
-	}
 	dense_test_dataset<float> ds;
-	ds.n = std::stoul(get("n", nullptr));
-	ds.m = std::stoul(get("m", nullptr));
-	ds.dim = std::stoul(get("d", nullptr));
-	ds.k = std::stoul(get("k", nullptr));
-	ds.name = get("ds_name", "synthetic");
 	const int device = std::stoi(get("device", "0"));
 	const std::string mode = get("mode", "both");  // serial | batched | both
-
-	std::mt19937 gen(1234);
-	std::normal_distribution<> nd(0, 1);
-	ds.all_vecs.resize(ds.n * ds.dim);
-	ds.all_query_vecs.resize(ds.m * ds.dim);
-	for (auto& x : ds.all_vecs) x = float(nd(gen));
-	for (auto& x : ds.all_query_vecs) x = float(nd(gen));
+	bool have_ground_truth = false;
+	if (dataset == "Sift1M") {
+		// src/main.cpp:72-80: fixed relative paths under datasets/sift/ (override: --sift_dir)
+		const std::string dir = get("sift_dir", "datasets/sift");
+		try {
+			ds = expann::load_sift1m(dir + "/sift_base.fvecs", dir + "/sift_query.fvecs",
+			                         dir + "/sift_groundtruth.ivecs", std::stoul(get("k", nullptr)));
+		} catch (const std::exception& e) {
+			std::fprintf(stderr, "error: %s\n", e.what());
+			return 1;
+		}
+		if (cli.count("m") && std::stoul(cli["m"]) < ds.m) {  // load_sift1m_custom, :170-181
+			ds.m = std::stoul(cli["m"]);
+			ds.all_query_vecs.resize(ds.m * ds.dim);
+			ds.all_query_ans.resize(ds.m);
+		}
+		have_ground_truth = true;
+	} else if (dataset == "Synthetic") {
+		ds.n = std::stoul(get("n", nullptr));
+		ds.m = std::stoul(get("m", nullptr));
+		ds.dim = std::stoul(get("d", nullptr));
+		ds.k = std::stoul(get("k", nullptr));
+		std::mt19937 gen(1234);
+		std::normal_distribution<> nd(0, 1);
+		ds.all_vecs.resize(ds.n * ds.dim);
+		ds.all_query_vecs.resize(ds.m * ds.dim);
+		for (auto& x : ds.all_vecs) x = float(nd(gen));
+		for (auto& x : ds.all_query_vecs) x = float(nd(gen));
+	} else {
+		std::fprintf(stderr, "Invalid dataset type!\n");  // src/main.cpp:90-93
+		return 1;
+	}
+	std::string ds_name = get("ds_name", "");
+	if (ds_name.empty())
+		ds_name = dataset;  // src/main.cpp:95-99
+	ds.name = ds_name;
 
 	try {
-		{  // ground truth = exact brute force (src/dataset_loader.h:27-38), on the GPU
+		if (!have_ground_truth) {  // exact brute force (src/dataset_loader.h:27-38), on the GPU
 			gpu_brute_force_engine<float>::config gcfg(device);
 			gpu_brute_force_engine<float> gt(gcfg);
 			gt.store_rows(ds.all_vecs.data(), ds.n, ds.dim);
@@ -122,6 +142,7 @@ int main(int argc, char** argv) {
 			            checksum, ds.n, ds.m, ds.dim, ds.k);
 		}
 		basic_bench<float, dense_test_dataset<float>> bench(ds);
+		expann::bench_data_manager bdm;
 		std::ofstream out;
 		if (cli.count("out")) out.open(cli["out"]);
 		if (mode == "serial" || mode == "both") {
@@ -129,6 +150,7 @@ int main(int argc, char** argv) {
 			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data(eng);
 			bd.param_list["mode"] = "serial";
+			bdm.add(bd);
 			std::printf("%s\n", bd.to_string().c_str());
 			if (out) out << bd.to_string() << "\n";
 		}
@@ -137,9 +159,12 @@ int main(int argc, char** argv) {
 			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data_batched(eng);
 			bd.param_list["mode"] = "batched";
+			bdm.add(bd);
 			std::printf("%s\n", bd.to_string().c_str());
 			if (out) out << bd.to_string() << "\n";
 		}
+		if (get("save", "0") == "1")  // src/main.cpp:101-106: ./data/<ds_name>/data/{latest,all}.json
+			bdm.save(get("data_root", "./data/") + ds_name + "/");
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "error: %s\n", e.what());
 		return 1;

@@ -38,3 +38,46 @@ def test_driver_rejects_missing_parameters(tmp_path):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
     out = subprocess.run([EXE, "--n", "100"], capture_output=True, text=True, cwd=tmp_path)
     assert out.returncode == 2 and "missing parameter" in out.stderr
+    out = subprocess.run([EXE, "--dataset", "Nope"], capture_output=True, text=True, cwd=tmp_path)
+    assert out.returncode == 1 and "Invalid dataset type" in out.stderr
+
+
+def _write_vecs(path, arr):
+    """fvecs/ivecs: per vector a 32-bit d then d 4-byte components (src/dataset_loader.h:96-125)."""
+    import numpy as np
+    n, d = arr.shape
+    rec = np.empty((n, d + 1), dtype=np.int32)
+    rec[:, 0] = d
+    rec[:, 1:] = arr.view(np.int32)
+    rec.tofile(path)
+
+
+def test_driver_sift1m_files_and_result_files(tmp_path, oracle):
+    """--dataset Sift1M: fvecs/ivecs files in the reference's layout, ground truth from the ivecs
+    file (here: the oracle's exact answers), results appended to data/<ds_name>/data/all.json and
+    written to latest.json like bench_data_manager::save (src/bench_data_manager.h:65-73)."""
+    import numpy as np
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    rng = np.random.RandomState(3)
+    base = np.clip(np.round(np.abs(rng.standard_normal((3000, 128))) * 40), 0, 255).astype(np.float32)
+    query = np.clip(np.round(np.abs(rng.standard_normal((25, 128))) * 40), 0, 255).astype(np.float32)
+    gt, _ = oracle.brute_force(base, query, 100)
+    sift = tmp_path / "sift"
+    sift.mkdir()
+    _write_vecs(sift / "sift_base.fvecs", base)
+    _write_vecs(sift / "sift_query.fvecs", query)
+    _write_vecs(sift / "sift_groundtruth.ivecs", gt.astype(np.int32))
+    args = [EXE, "--dataset", "Sift1M", "--ds_name", "mini_sift", "--num_threads", "1", "--k", "10",
+            "--sift_dir", str(sift), "--save", "1", "--data_root", str(tmp_path / "data") + "/",
+            "--mode", "batched"]
+    for _ in range(2):
+        out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+    bd = json.loads(out.stdout.strip().splitlines()[-1])
+    assert bd["recall"] == 1.0          # exact engine vs the file's exact ground truth
+    latest = json.load(open(tmp_path / "data" / "mini_sift" / "data" / "latest.json"))
+    allj = json.load(open(tmp_path / "data" / "mini_sift" / "data" / "all.json"))
+    assert len(latest) == 1 and len(allj) == 2 and allj[0]["engine_name"] == latest[0]["engine_name"]
+    assert set(latest[0]) == {"time_per_query_ns", "time_to_build_ns", "average_distance",
+                              "average_squared_distance", "recall", "engine_name", "param_list"}
