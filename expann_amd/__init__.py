@@ -5,5 +5,6 @@ into libexpann_hip.so) and the host-side mirror of the reference's engine interf
 """
 from . import _lib  # noqa: F401
 from .engine import GpuBruteForceEngine, merge_topk_device  # noqa: F401
+from .pyrunner import AntitopoEngine  # noqa: F401
 
-__all__ = ["GpuBruteForceEngine", "merge_topk_device"]
+__all__ = ["GpuBruteForceEngine", "merge_topk_device", "AntitopoEngine"]

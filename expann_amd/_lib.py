@@ -21,6 +21,10 @@ ABI_SYMBOLS = [
     "expann_quantize_simple_u8_device", "expann_quantize_ranged_q8_device",
     "expann_graph_create", "expann_graph_destroy", "expann_graph_last_error",
     "expann_graph_search", "expann_graph_last_kernel_ms",
+    "expann_antitopo_create", "expann_antitopo_destroy", "expann_antitopo_last_error",
+    "expann_antitopo_store", "expann_antitopo_build", "expann_antitopo_set_ef_search",
+    "expann_antitopo_query", "expann_antitopo_save", "expann_antitopo_load",
+    "expann_antitopo_size", "expann_antitopo_num_distcomps",
 ]
 
 
@@ -89,6 +93,28 @@ def load():
     L.expann_graph_search.argtypes = [vp, vp, sz, sz, sz, C.c_int, vp, vp, vp]
     L.expann_graph_last_kernel_ms.restype = C.c_double
     L.expann_graph_last_kernel_ms.argtypes = [vp]
+    L.expann_antitopo_create.restype = C.c_int
+    L.expann_antitopo_create.argtypes = [C.c_int, C.c_int, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
+    L.expann_antitopo_destroy.restype = None
+    L.expann_antitopo_destroy.argtypes = [vp]
+    L.expann_antitopo_last_error.restype = C.c_char_p
+    L.expann_antitopo_last_error.argtypes = [vp]
+    L.expann_antitopo_store.restype = C.c_int
+    L.expann_antitopo_store.argtypes = [vp, vp, sz]
+    L.expann_antitopo_build.restype = C.c_int
+    L.expann_antitopo_build.argtypes = [vp]
+    L.expann_antitopo_set_ef_search.restype = C.c_int
+    L.expann_antitopo_set_ef_search.argtypes = [vp, sz]
+    L.expann_antitopo_query.restype = C.c_int
+    L.expann_antitopo_query.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.expann_antitopo_save.restype = C.c_int
+    L.expann_antitopo_save.argtypes = [vp, C.c_char_p]
+    L.expann_antitopo_load.restype = C.c_int
+    L.expann_antitopo_load.argtypes = [vp, C.c_char_p]
+    L.expann_antitopo_size.restype = sz
+    L.expann_antitopo_size.argtypes = [vp]
+    L.expann_antitopo_num_distcomps.restype = u64
+    L.expann_antitopo_num_distcomps.argtypes = [vp]
     L.expann_set_profiling.restype = C.c_int
     L.expann_set_profiling.argtypes = [vp, C.c_int]
     L.expann_get_profile.restype = C.c_int

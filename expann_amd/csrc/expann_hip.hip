@@ -1385,6 +1385,116 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	return EXPANN_OK;
 }
 
+// ---- the graph engine behind one handle (host build + device queries) --------------------
+}  // extern "C"
+
+#include "expann/gpu_antitopo_engine.h"
+
+struct expann_antitopo {
+	gpu_antitopo_engine<float>* eng = nullptr;
+	int dim = 0;
+	mutable std::string err;
+	int fail(int code, const std::string& msg) const {
+		err = msg;
+		return code;
+	}
+};
+
+#define ANTITOPO_TRY(e, body)                                              \
+	try {                                                                  \
+		body;                                                              \
+	} catch (const std::exception& ex) {                                   \
+		return (e)->fail(EXPANN_ERR_INVALID_ARG, ex.what());               \
+	}
+
+extern "C" {
+
+int expann_antitopo_create(int dim, int device, size_t M, size_t ef_construction,
+                           size_t ortho_count, size_t prune_overflow, int use_compression,
+                           expann_antitopo** out) {
+	if (!out || dim <= 0 || dim % 64 != 0 || M < 2 || ef_construction == 0) {
+		g_create_error = "expann_antitopo_create: bad arguments (dim % 64 == 0, M >= 2)";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (expann_device_count() <= 0) {
+		g_create_error = "no HIP device visible: libexpann_hip has no CPU fallback";
+		return EXPANN_ERR_NO_DEVICE;
+	}
+	gpu_antitopo_engine_config cfg(M, 2 * M, 1, ef_construction, ortho_count, 0.5f, 0.0f,
+	                               prune_overflow, use_compression != 0);
+	cfg.device = device;
+	expann_antitopo* e = new expann_antitopo();
+	e->dim = dim;
+	e->eng = new gpu_antitopo_engine<float>(cfg);
+	e->eng->index.dim = (size_t)dim;
+	*out = e;
+	return EXPANN_OK;
+}
+
+void expann_antitopo_destroy(expann_antitopo* e) {
+	if (!e)
+		return;
+	delete e->eng;
+	delete e;
+}
+
+const char* expann_antitopo_last_error(const expann_antitopo* e) {
+	return e ? e->err.c_str() : g_create_error.c_str();
+}
+
+int expann_antitopo_store(expann_antitopo* e, const float* rows, size_t n) {
+	if (!e || (!rows && n))
+		return EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, for (size_t i = 0; i < n; ++i) e->eng->index.insert(rows + i * (size_t)e->dim));
+	return EXPANN_OK;
+}
+
+int expann_antitopo_build(expann_antitopo* e) {
+	if (!e)
+		return EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, e->eng->_build());
+	return EXPANN_OK;
+}
+
+int expann_antitopo_set_ef_search(expann_antitopo* e, size_t ef_search) {
+	if (!e || ef_search == 0)
+		return EXPANN_ERR_INVALID_ARG;
+	e->eng->set_ef_search(ef_search);
+	return EXPANN_OK;
+}
+
+int expann_antitopo_query(expann_antitopo* e, const float* queries, size_t m, size_t k,
+                          uint64_t* ids, float* dists) {
+	if (!e || !queries || !ids || !dists || k == 0)
+		return e ? e->fail(EXPANN_ERR_INVALID_ARG, "bad arguments") : EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, e->eng->query_k_batch(queries, m, k, ids, dists));
+	return EXPANN_OK;
+}
+
+int expann_antitopo_save(expann_antitopo* e, const char* index_path) {
+	if (!e || !index_path)
+		return EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, e->eng->index.write_index(index_path));
+	return EXPANN_OK;
+}
+
+int expann_antitopo_load(expann_antitopo* e, const char* index_path) {
+	if (!e || !index_path)
+		return EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, {
+		e->eng->index.read_index(index_path);
+		if ((int)e->eng->index.dim != e->dim)
+			throw std::runtime_error("index dimension differs from the engine's");
+		e->eng->upload();
+	});
+	return EXPANN_OK;
+}
+
+size_t expann_antitopo_size(const expann_antitopo* e) { return e ? e->eng->index.size() : 0; }
+uint64_t expann_antitopo_num_distcomps(const expann_antitopo* e) {
+	return e ? e->eng->num_distcomps : 0;
+}
+
 int expann_quantize_simple_u8_device(int device, const float* d_rows, size_t n_values,
                                      uint8_t* d_out, void* stream) {
 	if (!d_rows || !d_out) {

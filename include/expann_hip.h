@@ -128,6 +128,28 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 /* device time of the last expann_graph_search's traversal kernel, milliseconds */
 double expann_graph_last_kernel_ms(const expann_graph* g);
 
+/* the whole graph engine behind one handle (what src/pyrunner.cpp:56-90 binds: ctor,
+ * store_vector / store_many_vectors, build, query_k, set_ef_search).  Construction runs on the
+ * host (include/expann/antitopo_index.h), queries on the GPU (expann_graph_search). */
+typedef struct expann_antitopo expann_antitopo;
+/* antitopo_engine(M, ef_construction, ortho_count, prune_overflow, use_compression),
+ * src/antitopo_engine.h:157-166: M0 = 2M, ortho_factor = 0.5, ortho_bias = 0, ef_search_mult = 1 */
+int expann_antitopo_create(int dim, int device, size_t M, size_t ef_construction,
+                           size_t ortho_count, size_t prune_overflow, int use_compression,
+                           expann_antitopo** out);
+void expann_antitopo_destroy(expann_antitopo* e);
+const char* expann_antitopo_last_error(const expann_antitopo* e);
+int expann_antitopo_store(expann_antitopo* e, const float* rows, size_t n);  /* _store_vector x n */
+int expann_antitopo_build(expann_antitopo* e);                               /* _build (:467-493) */
+int expann_antitopo_set_ef_search(expann_antitopo* e, size_t ef_search);     /* :189-195 */
+/* query_k for a batch; ef_search defaults to k * ef_search_mult and is sticky (:858-859) */
+int expann_antitopo_query(expann_antitopo* e, const float* queries, size_t m, size_t k,
+                          uint64_t* ids, float* dists);
+int expann_antitopo_save(expann_antitopo* e, const char* index_path);  /* serialize, :932-991 */
+int expann_antitopo_load(expann_antitopo* e, const char* index_path);  /* deserialize + upload */
+size_t expann_antitopo_size(const expann_antitopo* e);
+uint64_t expann_antitopo_num_distcomps(const expann_antitopo* e);
+
 /* quantiser builds on device buffers (src/quantizer.h) -------------------------------- */
 /* quantizer_simple<uint8_t>::build (src/quantizer.h:132-141): out[i] = uint8_t(in[i]), no
  * scaling; defined for 0 <= in[i] < 256.  Asynchronous on `stream`. */

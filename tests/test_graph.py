@@ -70,3 +70,42 @@ def test_gpu_traversal_matches_oracle(tmp_path, oracle, data, d):
             assert np.array_equal(ids, oids), (comp, ef)
             assert np.array_equal(dists.view(np.uint32), odists.view(np.uint32)), (comp, ef)
             assert np.array_equal(dc.astype(np.uint64), odc), (comp, ef)
+
+
+@pytest.mark.gpu
+def test_python_module_surface(tmp_path, oracle):
+    """The pyrunner.cpp surface (AntitopoEngine): zero-padding to the engine dimension,
+    take_norms, sticky ef_search, index save / load round trip; results checked against the oracle
+    on the saved index."""
+    from expann_amd import AntitopoEngine
+    rng = np.random.RandomState(9)
+    base = rng.standard_normal((1200, 100)).astype(np.float32)     # 100 dims -> padded to 128
+    q = rng.standard_normal((20, 100)).astype(np.float32)
+    eng = AntitopoEngine(16, 80, 1, 0, False)
+    eng.store_many_vectors(base[:600], True)
+    for v in base[600:610]:
+        eng.store_vector(v / np.linalg.norm(v))
+    eng.store_many_vectors(base[610:], True)
+    assert eng.dim == 128 and eng.size() == 1200
+    eng.build()
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    ids10 = [eng.query_k_numpy(x, 10) for x in qn]                  # ef_search := 10, sticky
+    eng.set_ef_search(80)
+    ids80, d80 = eng.query_many(qn, 10)
+    idx = tmp_path / "py.index"
+    eng.save_index(idx)
+    g = oracle.Graph(str(idx))
+    qp = np.zeros((20, 128), np.float32)
+    qp[:, :100] = qn
+    o10, _, _ = g.query_k(qp, 10, 10)
+    o80, od80, _ = g.query_k(qp, 10, 80)
+    assert [[int(x) for x in r] for r in o10] == ids10
+    assert np.array_equal(ids80, o80) and np.array_equal(d80.view(np.uint32), od80.view(np.uint32))
+    eng2 = AntitopoEngine(16, 80, 1, 0, False, dim=128)
+    eng2.load_index(idx)
+    eng2.set_ef_search(80)
+    ids_b, _ = eng2.query_many(qn, 10)
+    assert np.array_equal(ids_b, ids80)
+    assert "M0" in eng.param_list() and int(eng.param_list()["num_distcomps"]) > 0
+    eng.close()
+    eng2.close()
