@@ -38,9 +38,11 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "i8", "u8"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c4"],
                     help="preset: c2 = BASELINE configs[1] (default, the headline metric); "
-                         "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric)")
+                         "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric); "
+                         "c4 = configs[3] graph search recall sweep (SIFT-like stand-in, "
+                         "--n rows, built on the host CPU first)")
     ap.add_argument("--query-tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
@@ -142,8 +144,63 @@ def profiled_traffic(kernel_name):
     return None, None
 
 
+def bench_c4(a):
+    """configs[3]: antitopo graph search, GPU candidate scoring + queues inside the traversal,
+    recall@k sweep over ef_search.  SIFT1M is not available offline: SIFT-like synthetic rows
+    (SURVEY 8d).  The graph is built by the host-side builder (the reference builds on the CPU
+    too and caches index files); the timed part is the batched query launch."""
+    import subprocess
+    import numpy as np
+    tool = os.path.join(ROOT, "expann_amd", "host", "expann_graph_tool")
+    out_dir = os.path.join(ROOT, "gpurun_out", "c4")
+    os.makedirs(out_dir, exist_ok=True)
+    n = a.n if a.n != 1_000_000 else 20_000
+    idx, qf = os.path.join(out_dir, "c4.index"), os.path.join(out_dir, "c4.queries")
+    efs = [a.k * mult for mult in (1, 2, 3, 4, 5, 6)]       # src/bench_runner.h:134
+    cmd = [tool, "--n", str(n), "--m", str(a.m), "--d", str(a.d), "--k", str(a.k), "--M", "16",
+           "--ef_construction", "100", "--data", "sift", "--index", idx, "--queries", qf,
+           "--ef", ",".join(map(str, efs))]
+    t0 = time.perf_counter()
+    res = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    lines = [json.loads(x) for x in res.stdout.strip().splitlines()]
+    build = lines[0]
+    sweep = [x for x in lines if x["phase"] == "query"]
+    best = max((x for x in sweep if x["use_compression"] == 0), key=lambda x: x["recall"])
+    gather_bytes = best["distcomps_per_query"] * a.d * 4 * a.m
+    ach = gather_bytes / (best["kernel_ms"] * 1e-3) / 1e9
+    out = {"metric": f"queries/sec at recall@{a.k} (graph search sweep), {n}xd{a.d} fp32 SIFT-like, k={a.k}",
+           "value": round(1e9 / best["time_per_query_ns"], 1), "unit": "queries/s", "n_gpus": 1,
+           "steps": 1, "warmup": 1, "ms_per_step": round(best["time_per_query_ns"] * a.m / 1e6, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"antitopo_engine graph search N={n} d={a.d}, M=16 M0=32 "
+                                  f"ef_construction=100, {a.m} batched queries, k={a.k} "
+                                  "(BASELINE configs[3], SIFT-like stand-in)",
+                      "recall": best["recall"], "ef_search": best["ef_search"],
+                      "build_s": round(build["time_to_build_ns"] / 1e9, 1), "sweep": sweep},
+           "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "graph_search<128,fp32>", "kernel_ms": best["kernel_ms"],
+                        "note": "random 512-B row gathers: latency-bound, not bandwidth-bound; "
+                                "algorithmic bytes = distcomps x d x 4 (SURVEY 8d)"}}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_ctypes as oc
+        g = oc.Graph(idx)
+        q = np.fromfile(qf, dtype=np.float32).reshape(-1, a.d)[:200]
+        t1 = time.perf_counter()
+        g.query_k(q, a.k, int(best["ef_search"]))
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(len(q) / dt, 1), "unit": "queries/s", "cores": 1,
+                               "kind": "port", "sample": f"{len(q)} queries, same index, same "
+                               f"ef_search={best['ef_search']} (oracle restatement of _query_k)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.workload == "c4":
+        return bench_c4(a)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

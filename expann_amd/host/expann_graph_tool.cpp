@@ -23,6 +23,7 @@
 #include <string>
 
 #include "expann/gpu_antitopo_engine.h"
+#include "expann/gpu_brute_force_engine.h"
 
 int main(int argc, char** argv) {
 	std::map<std::string, std::string> a;
@@ -85,6 +86,15 @@ int main(int argc, char** argv) {
 		}
 		if (build_only)
 			return 0;
+		// exact ground truth for the recall column (src/dataset_loader.h:27-38: brute force)
+		std::vector<uint64_t> gt(m * k);
+		{
+			gpu_brute_force_engine<float>::config bcfg(0);
+			gpu_brute_force_engine<float> bf(bcfg);
+			bf.store_rows(eng.index.vectors.data(), eng.index.size(), d);
+			bf.build();
+			bf.query_k_batch(queries.data(), m, k, gt.data(), nullptr);
+		}
 		std::vector<size_t> efs;
 		{
 			std::stringstream ss(get("ef", "10,20,40"));
@@ -108,11 +118,21 @@ int main(int argc, char** argv) {
 				auto q1 = std::chrono::high_resolution_clock::now();
 				double evals = 0;
 				for (auto x : dc) evals += x;
+				size_t found = 0;  // src/basic_bench.h:116-121,143
+				for (size_t q = 0; q < m; ++q)
+					for (size_t i = 0; i < k; ++i)
+						for (size_t j = 0; j < k; ++j)
+							if (ids[q * k + j] == gt[q * k + i]) {
+								++found;
+								break;
+							}
+				const double recall = double(found) / double(m * k);
 				std::printf("{\"phase\":\"query\",\"use_compression\":%d,\"ef_search\":%zu,"
-				            "\"time_per_query_ns\":%.1f,\"kernel_ms\":%.4f,\"distcomps_per_query\":%.1f}\n",
+				            "\"time_per_query_ns\":%.1f,\"kernel_ms\":%.4f,\"distcomps_per_query\":%.1f,"
+				            "\"recall\":%.4f}\n",
 				            comp, ef,
 				            double(std::chrono::duration_cast<std::chrono::nanoseconds>(q1 - q0).count()) / double(m),
-				            expann_graph_last_kernel_ms(eng.graph), evals / double(m));
+				            expann_graph_last_kernel_ms(eng.graph), evals / double(m), recall);
 				if (rf) {
 					rf.write(reinterpret_cast<const char*>(ids.data()), (std::streamsize)(ids.size() * 8));
 					rf.write(reinterpret_cast<const char*>(dists.data()), (std::streamsize)(dists.size() * 4));
