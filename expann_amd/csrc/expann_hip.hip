@@ -29,6 +29,20 @@ using namespace expann;
 
 namespace {
 
+// scoped device allocation for the entry points that need per-call temporaries
+struct DevBuf {
+	void* p = nullptr;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() {
+		if (p)
+			(void)hipFree(p);
+	}
+	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+	template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 thread_local std::string g_create_error;
 
 constexpr uint32_t kMaxCap = 16384;      // keys per query that fit the select kernel's LDS
@@ -1067,12 +1081,13 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 		if (ids[i] < h->id_offset || ids[i] - h->id_offset >= h->n)
 			return h->fail(EXPANN_ERR_INVALID_ARG, "id out of range");
 	HIP_TRY(h, hipSetDevice(h->device));
-	void *d_query = nullptr, *d_idl = nullptr, *d_sc = nullptr, *d_q8s = nullptr;
-	uint32_t* d_bad = nullptr;
+	DevBuf b_query, b_idl, b_sc, b_q8s, b_bad;
 	const size_t qb = (size_t)h->dim * h->q_elem;
-	HIP_TRY(h, hipMalloc(&d_query, qb));
-	HIP_TRY(h, hipMalloc(&d_idl, sizeof(uint64_t) * n_ids));
-	HIP_TRY(h, hipMalloc(&d_sc, sizeof(float) * n_ids));
+	HIP_TRY(h, b_query.alloc(qb));
+	HIP_TRY(h, b_idl.alloc(sizeof(uint64_t) * n_ids));
+	HIP_TRY(h, b_sc.alloc(sizeof(float) * n_ids));
+	void *d_query = b_query.p, *d_idl = b_idl.p, *d_sc = b_sc.p, *d_q8s = nullptr;
+	uint32_t* d_bad = nullptr;
 	HIP_TRY(h, hipMemcpyAsync(d_query, query, qb, hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(d_idl, ids, sizeof(uint64_t) * n_ids, hipMemcpyHostToDevice, h->stream));
 	const uint32_t blocks = (uint32_t)((n_ids + kRowsPerGroup - 1) / kRowsPerGroup);
@@ -1096,8 +1111,10 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 			return h->fail(EXPANN_ERR_UNSUPPORTED, "no 8-bit score kernel for this dim");
 		const void* qptr = d_query;
 		if (h->dtype == EXPANN_DTYPE_U8) {
-			HIP_TRY(h, hipMalloc(&d_q8s, (size_t)h->dim));
-			HIP_TRY(h, hipMalloc((void**)&d_bad, sizeof(uint32_t)));
+			HIP_TRY(h, b_q8s.alloc((size_t)h->dim));
+			HIP_TRY(h, b_bad.alloc(sizeof(uint32_t)));
+			d_q8s = b_q8s.p;
+			d_bad = b_bad.as<uint32_t>();
 			HIP_TRY(h, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), h->stream));
 			hipLaunchKernelGGL(u8_query_prep_kernel, dim3((uint32_t)((h->dim + kBlock - 1) / kBlock)),
 			                   dim3(kBlock), 0, h->stream, (const float*)d_query, (size_t)h->dim,
@@ -1114,11 +1131,6 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 	std::vector<float> sc(n_ids);
 	HIP_TRY(h, hipMemcpyAsync(sc.data(), d_sc, sizeof(float) * n_ids, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
-	hipFree(d_query);
-	hipFree(d_idl);
-	hipFree(d_sc);
-	if (d_q8s) hipFree(d_q8s);
-	if (d_bad) hipFree(d_bad);
 	if (bad_host)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "query values outside [0,255] for the uint8 metric");
 	size_t kept = 0;
@@ -1313,15 +1325,16 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 		                   g->d_compressed);
 		HIP_TRY(g, hipGetLastError());
 	}
-	float* d_q = nullptr;
-	uint64_t* d_ids = nullptr;
-	float* d_d = nullptr;
-	uint32_t* d_dc = nullptr;
+	DevBuf b_q, b_ids, b_d, b_dc;
 	const size_t qb = m * (size_t)g->dim * sizeof(float);
-	HIP_TRY(g, hipMalloc(&d_q, qb));
-	HIP_TRY(g, hipMalloc(&d_ids, sizeof(uint64_t) * m * k));
-	HIP_TRY(g, hipMalloc(&d_d, sizeof(float) * m * k));
-	HIP_TRY(g, hipMalloc(&d_dc, sizeof(uint32_t) * m));
+	HIP_TRY(g, b_q.alloc(qb));
+	HIP_TRY(g, b_ids.alloc(sizeof(uint64_t) * m * k));
+	HIP_TRY(g, b_d.alloc(sizeof(float) * m * k));
+	HIP_TRY(g, b_dc.alloc(sizeof(uint32_t) * m));
+	float* d_q = b_q.as<float>();
+	uint64_t* d_ids = b_ids.as<uint64_t>();
+	float* d_d = b_d.as<float>();
+	uint32_t* d_dc = b_dc.as<uint32_t>();
 	HIP_TRY(g, hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, g->stream));
 	HIP_TRY(g, hipMemsetAsync(g->d_error, 0, sizeof(uint32_t), g->stream));
 	uint32_t err_host = 0;
@@ -1378,10 +1391,6 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	HIP_TRY(g, hipMemcpy(dists, d_d, sizeof(float) * m * k, hipMemcpyDeviceToHost));
 	if (distcomps)
 		HIP_TRY(g, hipMemcpy(distcomps, d_dc, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
-	hipFree(d_q);
-	hipFree(d_ids);
-	hipFree(d_d);
-	hipFree(d_dc);
 	if (err_host)
 		return g->fail(EXPANN_ERR_OVERFLOW, "graph search: candidates queue overflowed its LDS capacity");
 	return EXPANN_OK;

@@ -90,7 +90,9 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
                   float* dists);
 
 /* same with device-resident queries and outputs, enqueued on `stream` (a hipStream_t;
- * NULL = the index's own stream).  Asynchronous unless the call reports an error. */
+ * NULL = the index's own stream).  The call returns after the stream has drained: the one host
+ * synchronisation of a search is the check that no internal candidate list overflowed (the
+ * search is re-run with larger lists / the tie-exact kernel if one did). */
 int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_t k,
                          uint64_t* d_ids, float* d_dists, void* stream);
 
