@@ -313,6 +313,15 @@ def main():
             tops = ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS,
                         "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
+        elif prof["scan_kernel"].startswith("scan_gemm_f16"):
+            # one fp16 MFMA product per fp32 product (scaled operands, rigorous slack, exact
+            # re-rank): executed flops = algorithmic 2*N*d*m, priced against the dense fp16 peak
+            alg = 2.0 * n_local * a.d * a.m
+            tf = alg / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "mfma_dtype": "fp16 (filter only; results exact after fp32 re-rank)",
+                        "algorithmic_vs_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 3)}
         elif prof["scan_kernel"].startswith("scan_gemm_bf16x3"):
             # fp32 products evaluated exactly enough on the bf16 cores as 3 bf16 MFMA products
             # (hi*hi + hi*lo + lo*hi): executed flops = 3 x the algorithmic 2*N*d*m

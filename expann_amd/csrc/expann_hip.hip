@@ -19,6 +19,7 @@
 #include "quantize.hpp"
 #include "scan_f32.hpp"
 #include "scan_gemm_bf16.hpp"
+#include "scan_gemm_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_int8.hpp"
@@ -84,8 +85,13 @@ struct expann_index {
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
 	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
 	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
-	void* d_q_split = nullptr;       // [m][2][dim] bf16
+	void* d_q_split = nullptr;       // [m][2][dim] bf16 (or [m][dim] fp16)
 	size_t q_split_bytes = 0;
+	void* d_base_f16 = nullptr;      // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
+	float* d_bnorm_f16 = nullptr;    // [n] ||b||^2 (1-eps) - abs |b|
+	float* d_qnrm = nullptr;         // [m_alloc] ||q||^2
+	float f16_scale = 0.0f;          // power of two; 0 = not built
+	float f16_bnmax = 0.0f;          // max ||b||^2 (host copy lives in d_bnmax[2])
 	float* d_theta = nullptr;        // [m_alloc] (int32 thetas for the 8-bit GEMM form)
 	int* d_bias_i = nullptr;         // [n] sum b^2 per row (8-bit L2 GEMM form), built lazily
 	int* d_qself = nullptr;          // [m_alloc]
@@ -279,6 +285,9 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		if (h->d_tau[1]) hipFree(h->d_tau[1]);
 		if (h->d_theta) hipFree(h->d_theta);
 		if (h->d_qself) hipFree(h->d_qself);
+		if (h->d_qnrm) hipFree(h->d_qnrm);
+		h->d_qnrm = nullptr;
+		HIP_TRY(h, hipMalloc(&h->d_qnrm, sizeof(float) * m));
 		h->d_cnt = nullptr;
 		h->d_theta = nullptr;
 		h->d_qself = nullptr;
@@ -335,6 +344,57 @@ struct GemmBf16Variant {
 const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16x3_kernel<64>, "scan_gemm_bf16x3<64>"},
                                      {128, scan_gemm_bf16x3_kernel<128>, "scan_gemm_bf16x3<128>"}};
 
+using GemmF16Fn = void (*)(GemmF16Params);
+using SqnormFn = void (*)(const float*, uint32_t, float*);
+struct GemmF16Variant {
+	int d;
+	GemmF16Fn scan;
+	SqnormFn sqnorm;
+	const char* name;
+};
+const GemmF16Variant kGemmF16[] = {{64, scan_gemm_f16_kernel<64>, sqnorm_kernel<64>, "scan_gemm_f16<64>"},
+                                   {128, scan_gemm_f16_kernel<128>, sqnorm_kernel<128>, "scan_gemm_f16<128>"}};
+
+// fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
+int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
+	if (h->d_base_f16)
+		return EXPANN_OK;
+	const size_t nv = h->n * (size_t)h->dim;
+	DevBuf tmp, nrm;
+	HIP_TRY(h, tmp.alloc(sizeof(float)));
+	HIP_TRY(h, nrm.alloc(sizeof(float) * h->n));
+	hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)h->d_base, nv,
+	                   tmp.as<float>());
+	float maxabs = 0.0f;
+	HIP_TRY(h, hipMemcpyAsync(&maxabs, tmp.p, sizeof(float), hipMemcpyDeviceToHost, st));
+	HIP_TRY(h, hipStreamSynchronize(st));
+	float scale = 1.0f;
+	if (maxabs > 0.0f && std::isfinite(maxabs)) {
+		int e = (int)std::floor(std::log2(32768.0 / (double)maxabs));
+		e = std::max(-100, std::min(100, e));
+		scale = std::ldexp(1.0f, e);
+	}
+	HIP_TRY(h, hipMalloc(&h->d_base_f16, nv * 2));
+	HIP_TRY(h, hipMalloc(&h->d_bnorm_f16, sizeof(float) * h->n));
+	if (!h->d_bnmax)
+		HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
+	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)), dim3(kBlock),
+	                   0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16);
+	const uint32_t blocks16 = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
+	hipLaunchKernelGGL(gf->sqnorm, dim3(blocks16), dim3(kBlock), 0, st, (const float*)h->d_base,
+	                   (uint32_t)h->n, nrm.as<float>());
+	hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)nrm.p, h->n,
+	                   h->d_bnmax + 2);
+	const float abs_coef = std::ldexp(1.0f, -24) / scale * std::sqrt((float)h->dim);
+	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
+	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(), abs_coef,
+	                   (const float*)nullptr, h->d_bnorm_f16);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
+	h->f16_scale = scale;
+	return EXPANN_OK;
+}
+
 const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
 		return nullptr;
@@ -357,7 +417,7 @@ int ensure_bnorm(expann_index* h, const GemmVariant* gv, bool bf16, hipStream_t 
 		hipLaunchKernelGGL(gv->norms, dim3(blocks), dim3(kBlock), 0, st, (const float*)h->d_base,
 		                   (uint32_t)h->n, 1.0f - eps, dst);
 		if (!h->d_bnmax)
-			HIP_TRY(h, hipMalloc(&h->d_bnmax, 2 * sizeof(float)));
+			HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
 		hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)dst, h->n,
 		                   h->d_bnmax + (bf16 ? 1 : 0));
 		HIP_TRY(h, hipGetLastError());
@@ -466,6 +526,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		                                           std::to_string(kMaxCap / 2) + ")");
 	const int cus = num_cus(h->device);
 	bool force_direct = false;  // set when a GEMM-form filter overflowed: massive near-ties
+	bool no_f16 = false;        // set when the queries do not fit the fp16 range of this index
 restart_direct:
 	const GemmVariant* gv = force_direct ? nullptr : pick_gemm(h, m);
 	const GemmI8Variant* gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
@@ -484,10 +545,46 @@ restart_direct:
 				gvb = &v;
 	if (h->opt_scan_kernel == 3 && !gvb)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "bf16x3 GEMM-form scan: f32 L2 with dim 64 or 128 only");
-	if (gv) {
+	// fp16 single-product form: default when available; a search whose queries leave the fp16
+	// range after scaling is redone with the bf16x3 form (no_f16)
+	const GemmF16Variant* gvf = nullptr;
+	if (gv && !no_f16 && (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4))
+		for (const auto& v : kGemmF16)
+			if (v.d == h->dim)
+				gvf = &v;
+	if (h->opt_scan_kernel == 4 && !gvf && !no_f16)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64 or 128 only");
+	if (gvf)
+		gvb = nullptr;
+	if (gv && !gvf) {
 		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
 		if (rc != EXPANN_OK)
 			return rc;
+	}
+	if (gvf) {
+		int rc = ensure_f16(h, gvf, st);
+		if (rc != EXPANN_OK)
+			return rc;
+		rc = ensure_workspace(h, m, cap);
+		if (rc != EXPANN_OK)
+			return rc;
+		const size_t nv = m * (size_t)h->dim;
+		if (nv * 4 > h->q_split_bytes) {
+			if (h->d_q_split) hipFree(h->d_q_split);
+			h->d_q_split = nullptr;
+			h->q_split_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_q_split, nv * 4));
+			h->q_split_bytes = nv * 4;
+		}
+		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end)
+		hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->f16_scale,
+		                   (_Float16*)h->d_q_split);
+		hipLaunchKernelGGL(gvf->sqnorm, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+		                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m, h->d_qnrm);
+		hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)d_queries, nv,
+		                   h->d_bnmax + 3);
+		HIP_TRY(h, hipGetLastError());
 	}
 	if (gvb) {  // queries -> bf16 hi/lo planes
 		const size_t nv = m * (size_t)h->dim;
@@ -543,11 +640,18 @@ restart_direct:
 			uint32_t qt_used = (uint32_t)sv->tq;
 			if (use_gemm) {
 				// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
-				hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
-				                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
-				                   (const float*)sp.tau,
-				                   1.0f - (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)),
-				                   h->d_theta);
+				const float f16_abs = gvf ? std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
+				                          : 0.0f;
+				if (gvf)
+					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
+					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
+					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau, h->d_theta);
+				else
+					hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+					                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
+					                   (const float*)sp.tau,
+					                   1.0f - (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)),
+					                   h->d_theta);
 				GemmScanParams gp{};
 				gp.base = (const float*)h->d_base;
 				gp.bnorm = h->d_bnorm;
@@ -556,7 +660,7 @@ restart_direct:
 				gp.n_tiles_sel = last ? n_tiles
 				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
 				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				const uint32_t tq_wg = gvb ? kGemmBf16TQ : kGemmTQ;
+				const uint32_t tq_wg = (gvb || gvf) ? kGemmBf16TQ : kGemmTQ;
 				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
 				gp.queries = (const float*)d_queries;
 				gp.theta = h->d_theta;
@@ -586,7 +690,31 @@ restart_direct:
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				if (gvb) {
+				if (gvf) {
+					GemmF16Params fp{};
+					fp.base_f16 = h->d_base_f16;
+					fp.bnorm = h->d_bnorm_f16;
+					fp.n_rows = gp.n_rows;
+					fp.n_tiles_sel = gp.n_tiles_sel;
+					fp.tile_stride = gp.tile_stride;
+					fp.tile_run = 1;
+					if (!last && gp.tile_stride >= 8 && gp.n_tiles_sel >= 8) {
+						fp.tile_run = 8;
+						fp.n_tiles_sel = (gp.n_tiles_sel / 8) * 8;
+					}
+					fp.tiles_per_block = gp.tiles_per_block;
+					fp.n_qtiles = gp.n_qtiles;
+					fp.queries_f16 = h->d_q_split;
+					fp.theta = gp.theta;
+					fp.neg2_inv_s2 = -2.0f / (h->f16_scale * h->f16_scale);
+					fp.m = gp.m;
+					fp.cand_cnt = gp.cand_cnt;
+					fp.cand = gp.cand;
+					fp.cap = gp.cap;
+					hipLaunchKernelGGL(gvf->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+					                   2 * kGemmTB * h->dim * 2, st, fp);
+					kname = gvf->name;
+				} else if (gvb) {
 					GemmBf16Params bp{};
 					bp.base_split = h->d_base_split;
 					bp.bnorm = h->d_bnorm_bf;
@@ -704,8 +832,13 @@ restart_direct:
 			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
 			sel.dim = (uint32_t)h->dim;
 			sel.metric_ip = ip ? 1u : 0u;
-			sel.prune_eps = use_gemm ? (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)) : 0.0f;
-			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvb ? 1 : 0) : nullptr;
+			sel.prune_eps = use_gemm ? (gvf ? 2.0f * gemm_f16_filter_eps()
+			                                : (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)))
+			                         : 0.0f;
+			sel.prune_abs = (use_gemm && gvf)
+			                    ? 2.0f * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
+			                    : 0.0f;
+			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
 			sel.overflow = h->d_overflow;
 			sel.total_cand = last ? h->d_total : nullptr;
 			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
@@ -721,6 +854,15 @@ restart_direct:
 		unsigned long long tot;
 		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
 		h->prof.candidates = tot;
+		if (gvf) {  // queries outside the fp16 range of this index: redo with the bf16x3 form
+			float qmax = 0.0f;
+			HIP_TRY(h, hipMemcpy(&qmax, h->d_bnmax + 3, sizeof(float), hipMemcpyDeviceToHost));
+			if (!(qmax * h->f16_scale <= 60000.0f)) {
+				no_f16 = true;
+				h->prof.retries++;
+				goto restart_direct;
+			}
+		}
 		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
 			return h->fail(EXPANN_ERR_UNSUPPORTED,
 			               std::to_string(h->h_flags[1]) +
@@ -836,6 +978,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		delete h;
 		return EXPANN_ERR_HIP;
 	}
+	for (const auto& v : kGemmF16)
+		if (v.d == dim)
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        2 * kGemmTB * dim * 2) != hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
 	for (const auto& v : kGemmBf16)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -883,6 +1034,9 @@ void expann_destroy(expann_index* h) {
 	if (h->d_bnorm) hipFree(h->d_bnorm);
 	if (h->d_bnorm_bf) hipFree(h->d_bnorm_bf);
 	if (h->d_bnmax) hipFree(h->d_bnmax);
+	if (h->d_base_f16) hipFree(h->d_base_f16);
+	if (h->d_bnorm_f16) hipFree(h->d_bnorm_f16);
+	if (h->d_qnrm) hipFree(h->d_qnrm);
 	if (h->d_base_split) hipFree(h->d_base_split);
 	if (h->d_q_split) hipFree(h->d_q_split);
 	if (h->d_bias_i) hipFree(h->d_bias_i);
@@ -964,6 +1118,15 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 		hipFree(h->d_base_split);
 		h->d_base_split = nullptr;
 	}
+	if (h->d_base_f16) {
+		hipFree(h->d_base_f16);
+		h->d_base_f16 = nullptr;
+	}
+	if (h->d_bnorm_f16) {
+		hipFree(h->d_bnorm_f16);
+		h->d_bnorm_f16 = nullptr;
+	}
+	h->f16_scale = 0.0f;
 	h->d_base = const_cast<void*>(d_rows);
 	h->owns_base = false;
 	h->n = n;

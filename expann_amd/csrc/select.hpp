@@ -32,6 +32,7 @@ struct SelectParams {
 	// candidate whose A exceeds the k-th smallest A by more than eps*(qn + 1.5*bn_max) cannot be
 	// among the k best and need not be re-scored.  prune_eps == 0 disables it.
 	float prune_eps;
+	float prune_abs;          // absolute slack coefficient (fp16 form): + prune_abs*(|q| + |b|max)
 	const float* bn_max;      // [1] max over rows of ||b||^2 (1-eps)
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
 	unsigned long long* total_cand;  // [1] sum of counts (statistics) or nullptr
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 			for (uint32_t t = 0; t < p.dim / 16; ++t)
 				qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
 			qn = reduce16_ref_order(qn);
-			const float cutoff = key_score(keys[p.k - 1]) + p.prune_eps * (qn + 1.5f * p.bn_max[0]);
+			const float bmax = p.bn_max[0];
+			const float cutoff = key_score(keys[p.k - 1]) + p.prune_eps * (qn + 1.5f * bmax) +
+			                     p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
 			uint32_t cnt = 0;
 			for (uint32_t i = tid; i < c; i += kBlock)
 				cnt += key_score(keys[i]) <= cutoff ? 1u : 0u;
