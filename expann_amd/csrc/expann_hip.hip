@@ -357,29 +357,35 @@ const GemmF16Variant kGemmF16[] = {{64, scan_gemm_f16_kernel<64>, sqnorm_kernel<
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
-	if (h->d_base_f16)
+	if (h->d_base_f16 || h->f16_scale < 0.0f)
 		return EXPANN_OK;
 	const size_t nv = h->n * (size_t)h->dim;
 	DevBuf tmp, nrm;
 	HIP_TRY(h, tmp.alloc(sizeof(float)));
 	HIP_TRY(h, nrm.alloc(sizeof(float) * h->n));
-	hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)h->d_base, nv,
-	                   tmp.as<float>());
-	float maxabs = 0.0f;
+	HIP_TRY(h, hipMemsetAsync(tmp.p, 0, sizeof(uint32_t), st));
+	hipLaunchKernelGGL(maxabs_bits_kernel, dim3(2048), dim3(kBlock), 0, st, (const float*)h->d_base, nv,
+	                   tmp.as<uint32_t>());
+	float maxabs = 0.0f;  // (a NaN pattern stays a NaN and fails the range check below)
 	HIP_TRY(h, hipMemcpyAsync(&maxabs, tmp.p, sizeof(float), hipMemcpyDeviceToHost, st));
 	HIP_TRY(h, hipStreamSynchronize(st));
 	float scale = 1.0f;
 	if (maxabs > 0.0f && std::isfinite(maxabs)) {
 		int e = (int)std::floor(std::log2(32768.0 / (double)maxabs));
-		e = std::max(-100, std::min(100, e));
+		e = std::max(-40, std::min(40, e));  // s^2 and every scaled norm stay finite in fp32
 		scale = std::ldexp(1.0f, e);
+	}
+	if (!(maxabs * scale <= 32768.0f)) {  // non-finite or astronomically large values
+		h->f16_scale = -1.0f;
+		return EXPANN_OK;
 	}
 	HIP_TRY(h, hipMalloc(&h->d_base_f16, nv * 2));
 	HIP_TRY(h, hipMalloc(&h->d_bnorm_f16, sizeof(float) * h->n));
 	if (!h->d_bnmax)
 		HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
 	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)), dim3(kBlock),
-	                   0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16);
+	                   0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16,
+	                   (uint32_t*)nullptr);
 	const uint32_t blocks16 = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
 	hipLaunchKernelGGL(gf->sqnorm, dim3(blocks16), dim3(kBlock), 0, st, (const float*)h->d_base,
 	                   (uint32_t)h->n, nrm.as<float>());
@@ -388,7 +394,7 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	const float abs_coef = std::ldexp(1.0f, -24) / scale * std::sqrt((float)h->dim);
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(), abs_coef,
-	                   (const float*)nullptr, h->d_bnorm_f16);
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
 	h->f16_scale = scale;
@@ -565,6 +571,10 @@ restart_direct:
 		int rc = ensure_f16(h, gvf, st);
 		if (rc != EXPANN_OK)
 			return rc;
+		if (h->f16_scale < 0.0f) {  // the index does not fit the fp16 range at any allowed scale
+			no_f16 = true;
+			goto restart_direct;
+		}
 		rc = ensure_workspace(h, m, cap);
 		if (rc != EXPANN_OK)
 			return rc;
@@ -577,13 +587,12 @@ restart_direct:
 			h->q_split_bytes = nv * 4;
 		}
 		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end)
+		HIP_TRY(h, hipMemsetAsync(h->d_bnmax + 3, 0, sizeof(uint32_t), st));
 		hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->f16_scale,
-		                   (_Float16*)h->d_q_split);
+		                   (_Float16*)h->d_q_split, (uint32_t*)(h->d_bnmax + 3));
 		hipLaunchKernelGGL(gvf->sqnorm, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m, h->d_qnrm);
-		hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)d_queries, nv,
-		                   h->d_bnmax + 3);
 		HIP_TRY(h, hipGetLastError());
 	}
 	if (gvb) {  // queries -> bf16 hi/lo planes
@@ -645,7 +654,8 @@ restart_direct:
 				if (gvf)
 					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
 					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
-					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau, h->d_theta);
+					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau,
+					                   0.5f * h->f16_scale * h->f16_scale, h->d_theta);
 				else
 					hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 					                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
@@ -706,13 +716,15 @@ restart_direct:
 					fp.n_qtiles = gp.n_qtiles;
 					fp.queries_f16 = h->d_q_split;
 					fp.theta = gp.theta;
-					fp.neg2_inv_s2 = -2.0f / (h->f16_scale * h->f16_scale);
+					fp.two_inv_s2 = 2.0f / (h->f16_scale * h->f16_scale);
 					fp.m = gp.m;
 					fp.cand_cnt = gp.cand_cnt;
 					fp.cand = gp.cand;
 					fp.cap = gp.cap;
+					fp.debug = (uint32_t)h->opt_debug;
 					hipLaunchKernelGGL(gvf->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-					                   2 * kGemmTB * h->dim * 2, st, fp);
+					                   h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>(),
+					                   st, fp);
 					kname = gvf->name;
 				} else if (gvb) {
 					GemmBf16Params bp{};
@@ -981,7 +993,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	for (const auto& v : kGemmF16)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        2 * kGemmTB * dim * 2) != hipSuccess) {
+			                        dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>()) !=
+			    hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
