@@ -85,6 +85,8 @@ struct expann_index {
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
 	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
 	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
+	float* d_sample = nullptr;       // [m][n_chunks][32] class maxima of the fp16 sample pass
+	size_t sample_bytes = 0;
 	void* d_q_split = nullptr;       // [m][2][dim] bf16 (or [m][dim] fp16)
 	size_t q_split_bytes = 0;
 	void* d_base_f16 = nullptr;      // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
@@ -102,6 +104,7 @@ struct expann_index {
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
 	long opt_debug = 0;
+	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
@@ -349,11 +352,14 @@ using SqnormFn = void (*)(const float*, uint32_t, float*);
 struct GemmF16Variant {
 	int d;
 	GemmF16Fn scan;
+	GemmF16Fn sample;
 	SqnormFn sqnorm;
 	const char* name;
 };
-const GemmF16Variant kGemmF16[] = {{64, scan_gemm_f16_kernel<64>, sqnorm_kernel<64>, "scan_gemm_f16<64>"},
-                                   {128, scan_gemm_f16_kernel<128>, sqnorm_kernel<128>, "scan_gemm_f16<128>"}};
+const GemmF16Variant kGemmF16[] = {
+    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>, "scan_gemm_f16<64>"},
+    {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
+     "scan_gemm_f16<128>"}};
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
@@ -379,12 +385,16 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 		h->f16_scale = -1.0f;
 		return EXPANN_OK;
 	}
-	HIP_TRY(h, hipMalloc(&h->d_base_f16, nv * 2));
-	HIP_TRY(h, hipMalloc(&h->d_bnorm_f16, sizeof(float) * h->n));
+	// padded to whole 64-row tiles: zero rows whose bn' is NaN (never a candidate)
+	const size_t n_pad = (h->n + kF16TB - 1) / kF16TB * kF16TB;
+	HIP_TRY(h, hipMalloc(&h->d_base_f16, n_pad * h->dim * 2));
+	HIP_TRY(h, hipMalloc(&h->d_bnorm_f16, sizeof(float) * n_pad));
+	HIP_TRY(h, hipMemsetAsync(h->d_base_f16, 0, n_pad * h->dim * 2, st));
+	HIP_TRY(h, hipMemsetAsync(h->d_bnorm_f16, 0xFF, sizeof(float) * n_pad, st));  // 0xFFFFFFFF: a NaN
 	if (!h->d_bnmax)
 		HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
-	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)), dim3(kBlock),
-	                   0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16,
+	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 8192)),
+	                   dim3(kBlock), 0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16,
 	                   (uint32_t*)nullptr);
 	const uint32_t blocks16 = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
 	hipLaunchKernelGGL(gf->sqnorm, dim3(blocks16), dim3(kBlock), 0, st, (const float*)h->d_base,
@@ -588,7 +598,8 @@ restart_direct:
 		}
 		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end)
 		HIP_TRY(h, hipMemsetAsync(h->d_bnmax + 3, 0, sizeof(uint32_t), st));
-		hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		hipLaunchKernelGGL(convert_f16_kernel,
+		                   dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->f16_scale,
 		                   (_Float16*)h->d_q_split, (uint32_t*)(h->d_bnmax + 3));
 		hipLaunchKernelGGL(gvf->sqnorm, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
@@ -618,7 +629,62 @@ restart_direct:
 		const uint32_t n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
 		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
 		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
-		for (size_t li = 0; li < levels.size(); ++li) {
+		// fp16 form on a large index: ONE sampled pass (1/16 of the rows, class maxima per query,
+		// scan_gemm_f16.hpp) gives the threshold of the full scan -- no direct level-0 scan, no
+		// intermediate candidate lists and selects
+		size_t li_start = 0;
+		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
+			const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
+			const uint32_t run = 16;
+			uint32_t t_sel = std::max<uint32_t>(256, nt / 16) / run * run;
+			const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
+			uint32_t chunks = std::max<uint32_t>(1, (2 * (uint32_t)cus) / nqt);
+			chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
+			chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
+			if (t_sel * 2 <= nt && (size_t)chunks * 32 >= 8 * k) {
+				const size_t need = m * (size_t)chunks * 32 * sizeof(float);
+				if (need > h->sample_bytes) {
+					if (h->d_sample) hipFree(h->d_sample);
+					h->d_sample = nullptr;
+					h->sample_bytes = 0;
+					HIP_TRY(h, hipMalloc(&h->d_sample, need));
+					h->sample_bytes = need;
+				}
+				GemmF16Params fp{};
+				fp.base_f16 = h->d_base_f16;
+				fp.bnorm = h->d_bnorm_f16;
+				fp.n_rows = (uint32_t)h->n;
+				fp.n_tiles_sel = t_sel;
+				fp.tile_stride = nt / t_sel;
+				fp.tile_run = run;
+				fp.tiles_per_block = (t_sel + chunks - 1) / chunks;
+				chunks = (t_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
+				fp.n_qtiles = nqt;
+				fp.queries_f16 = h->d_q_split;
+				fp.m = (uint32_t)m;
+				fp.sample_out = h->d_sample;
+				fp.n_chunks = chunks;
+				hipLaunchKernelGGL(gvf->sample, dim3(chunks * nqt), dim3(kF16Threads),
+				                   h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>(), st, fp);
+				li_start = levels.size() - 1;
+				SampleTauParams tp{};
+				tp.vals = h->d_sample;
+				tp.n_vals = chunks * 32;
+				tp.m = (uint32_t)m;
+				tp.k = (uint32_t)k;
+				tp.qnrm = h->d_qnrm;
+				tp.bn_max = h->d_bnmax + 2;
+				tp.eps = gemm_f16_filter_eps();
+				tp.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
+				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
+				tp.tau = h->d_tau[(li_start + 1) & 1];
+				tp.tau_row = h->d_tau_row[(li_start + 1) & 1];
+				hipLaunchKernelGGL(sample_tau_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
+				                   dim3(kBlock), 0, st, tp);
+				HIP_TRY(h, hipGetLastError());
+			}
+		}
+		for (size_t li = li_start; li < levels.size(); ++li) {
 			const Level& L = levels[li];
 			const bool first = (li == 0), last = (li + 1 == levels.size());
 			ScanParams sp{};
@@ -701,19 +767,39 @@ restart_direct:
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
 				if (gvf) {
+					// 64-row tiles, 256 queries per workgroup, two workgroups resident per CU
 					GemmF16Params fp{};
 					fp.base_f16 = h->d_base_f16;
 					fp.bnorm = h->d_bnorm_f16;
 					fp.n_rows = gp.n_rows;
-					fp.n_tiles_sel = gp.n_tiles_sel;
-					fp.tile_stride = gp.tile_stride;
+					const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
+					fp.n_tiles_sel = last ? nt : std::min(nt, (L.n_groups_sel * kRowsPerGroup + kF16TB - 1) / kF16TB);
+					fp.tile_stride = std::max<uint32_t>(1, nt / fp.n_tiles_sel);
 					fp.tile_run = 1;
-					if (!last && gp.tile_stride >= 8 && gp.n_tiles_sel >= 8) {
-						fp.tile_run = 8;
-						fp.n_tiles_sel = (gp.n_tiles_sel / 8) * 8;
+					if (!last && fp.tile_stride >= 16 && fp.n_tiles_sel >= 16) {
+						// sampled level: runs of 16 consecutive tiles (one 256 KiB stretch each at d = 128)
+						fp.tile_run = 16;
+						fp.n_tiles_sel = (fp.n_tiles_sel / 16) * 16;
 					}
-					fp.tiles_per_block = gp.tiles_per_block;
-					fp.n_qtiles = gp.n_qtiles;
+					fp.n_qtiles = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
+					uint32_t fchunks = 1;
+					{
+						const uint32_t slots = 2 * (uint32_t)cus;
+						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
+						double best = 1e300;
+						for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
+							const uint32_t steps = (fp.n_tiles_sel + g - 1) / g;
+							const uint64_t blocks = (uint64_t)g * fp.n_qtiles;
+							const uint64_t rounds = (blocks + slots - 1) / slots;
+							const double cost = (double)rounds * (steps + 4.0);
+							if (cost < best * 0.999) {
+								best = cost;
+								fchunks = g;
+							}
+						}
+					}
+					fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;
+					fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
 					fp.queries_f16 = h->d_q_split;
 					fp.theta = gp.theta;
 					fp.two_inv_s2 = 2.0f / (h->f16_scale * h->f16_scale);
@@ -721,11 +807,31 @@ restart_direct:
 					fp.cand_cnt = gp.cand_cnt;
 					fp.cand = gp.cand;
 					fp.cap = gp.cap;
-					fp.debug = (uint32_t)h->opt_debug;
-					hipLaunchKernelGGL(gvf->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+					fp.debug = (uint32_t)h->opt_debug & ~16u;
+					DevBuf clk;
+					if (h->opt_debug & 16) {
+						HIP_TRY(h, clk.alloc(18 * 8));
+						HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
+						fp.clk = clk.as<unsigned long long>();
+					}
+					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3(kF16Threads),
 					                   h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>(),
 					                   st, fp);
 					kname = gvf->name;
+					gp.n_qtiles = fp.n_qtiles;
+					if (fp.clk) {
+						unsigned long long c[18] = {0};
+						HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
+						std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
+						             c[1] / 100.0, c[1] ? c[0] * 100.0 / c[1] : 0.0);
+						for (int w = 0; w < 2; ++w) {
+							std::fprintf(stderr, "  wave %d step 100 stamps (top, staged, pre-epi, mfma issued, epi, "
+							                     "barrier, flush):", w * 2);
+							for (int i = 0; i < 7; ++i)
+								std::fprintf(stderr, " %lld", (long long)(c[2 + w * 8 + i] - c[2]));
+							std::fprintf(stderr, "\n");
+						}
+					}
 				} else if (gvb) {
 					GemmBf16Params bp{};
 					bp.base_split = h->d_base_split;
@@ -822,7 +928,7 @@ restart_direct:
 				h->prof.scan_rows += h->n;
 				h->prof.scan_query_tiles += passes;
 				h->prof.query_tile = qt_used;
-				h->prof.levels = (uint32_t)levels.size();
+				h->prof.levels = (uint32_t)(levels.size() - li_start + (li_start ? 1 : 0));
 				std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", kname);
 			}
 			HIP_TRY(h, hipGetLastError());
@@ -994,7 +1100,10 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
 			                        dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>()) !=
-			    hipSuccess) {
+			        hipSuccess ||
+			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>()) !=
+			        hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
@@ -1050,6 +1159,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_base_f16) hipFree(h->d_base_f16);
 	if (h->d_bnorm_f16) hipFree(h->d_bnorm_f16);
 	if (h->d_qnrm) hipFree(h->d_qnrm);
+	if (h->d_sample) hipFree(h->d_sample);
 	if (h->d_base_split) hipFree(h->d_base_split);
 	if (h->d_q_split) hipFree(h->d_q_split);
 	if (h->d_bias_i) hipFree(h->d_bias_i);
@@ -1787,6 +1897,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_debug = value;
 	else if (!std::strcmp(name, "scan_kernel"))
 		h->opt_scan_kernel = value;
+	else if (!std::strcmp(name, "sample_pass"))
+		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "sample_ratio"))
 		h->opt_sample_ratio = value < 2 ? 2 : value;
 	else

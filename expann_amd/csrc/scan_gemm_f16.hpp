@@ -14,15 +14,20 @@
 // to the direct scan.  Queries whose scaled components would leave the fp16 range make the
 // engine use the bf16x3 form for that search.
 //
-// Layout / geometry: rows of d fp16 (2d bytes), staged by LDS-DMA as in scan_gemm_bf16.hpp; 256
-// queries x 128 rows per workgroup step; 8 waves as 4 (query groups of 64) x 2 (row halves of
-// 64), each wave 2x2 MFMA tiles with its 64 queries' fragments in registers, so a row fragment
-// read from LDS feeds two MFMAs (LDS read traffic = half the MFMA pipe time at d = 128).
+// Layout / geometry: rows of d fp16 (2d bytes), staged by LDS-DMA as in scan_gemm_bf16.hpp.  A
+// workgroup is 4 waves = 256 queries x 64 rows per step; each wave holds its 64 queries'
+// fragments in registers and runs 2x2 MFMA tiles per step, so a row fragment read from LDS
+// feeds two MFMAs.  Two workgroups share a CU (<= 80 KB of LDS, <= 256 VGPRs): the two waves on
+// a SIMD belong to different workgroups with separate barriers, so one workgroup's barrier /
+// epilogue / flush bubbles are covered by the other's MFMAs.
 //
 // The test  bn - 2 q.b <= theta_q  runs in the scaled domain: the accumulators START at
 // theta'_q = theta_q s^2/2, the MFMAs add q16.b16, and a row passes when  acc >= bn'_b =
 // bn_b s^2/2  -- one compare per pair, folded per lane into a v_max3 tree per 32x32 tile, so
 // the common (no candidate) path costs 9 VALU instructions per tile.
+//
+// The fp16 copy of the index is padded to a multiple of 64 rows (zero rows whose bn' is NaN:
+// no accumulator compares >= NaN), so staging needs no bounds handling.
 #pragma once
 #include "common.hpp"
 #include "scan_gemm_bf16.hpp"
@@ -39,20 +44,29 @@ __host__ __device__ inline float gemm_f16_filter_eps() { return 1.125f * 0.00097
 __global__ __launch_bounds__(kBlock) void convert_f16_kernel(const float* in, size_t n_values,
                                                              float scale, _Float16* out,
                                                              uint32_t* maxabs_bits) {
-	const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-	float v = 0.0f;
-	if (i < n_values) {
-		v = in[i];
+	uint32_t b = 0;
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_values;
+	     i += (size_t)gridDim.x * kBlock) {
+		const float v = in[i];
 		out[i] = (_Float16)(v * scale);
+		const uint32_t vb = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
+		b = vb > b ? vb : b;
 	}
-	if (maxabs_bits) {
-		uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
+	if (maxabs_bits) {  // one atomic per workgroup
+		__shared__ uint32_t red[kBlock / 64];
 		for (int off = 32; off > 0; off >>= 1) {
 			const uint32_t o = (uint32_t)__shfl_xor((int)b, off);
 			b = o > b ? o : b;
 		}
-		if ((threadIdx.x & 63) == 0 && b != 0)
-			atomicMax(maxabs_bits, b);
+		if ((threadIdx.x & 63) == 0)
+			red[threadIdx.x >> 6] = b;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			for (int w = 1; w < kBlock / 64; ++w)
+				b = red[w] > b ? red[w] : b;
+			if (b != 0)
+				atomicMax(maxabs_bits, b);
+		}
 	}
 }
 
@@ -102,8 +116,8 @@ __global__ __launch_bounds__(kBlock) void f16_terms_kernel(const float* nrm, uin
 }
 
 struct GemmF16Params {
-	const void* base_f16;    // [n_rows][D] fp16, scaled by s
-	const float* bnorm;      // [n_rows] (||b||^2 (1-eps) - abs*|b|) * s^2/2
+	const void* base_f16;    // [n_rows padded to 64][D] fp16, scaled by s
+	const float* bnorm;      // [n_rows padded to 64] (||b||^2 (1-eps) - abs*|b|) * s^2/2; NaN padding
 	uint32_t n_rows;
 	uint32_t n_tiles_sel;
 	uint32_t tile_stride;
@@ -117,7 +131,12 @@ struct GemmF16Params {
 	uint32_t* cand_cnt;
 	uint64_t* cand;
 	uint32_t cap;
-	uint32_t debug;          // ablation switches (bench only): 1 no staging, 2 no MFMA, 4 no epilogue
+	uint32_t debug;          // ablation switches (bench only): 4 no epilogue, 8 no candidate path
+	unsigned long long* clk; // [2] debug: shader-clock and 100 MHz ticks of workgroup 0 (or nullptr)
+	// SAMPLE variant: out[(q * n_chunks + chunk) * 32 + c] = max over the chunk's rows of class c
+	// (row mod 32) of g = q16.b16 - bn'  (larger g = nearer row); theta, cand* unused
+	float* sample_out;
+	uint32_t n_chunks;
 };
 
 __device__ inline float max3f(float a, float b, float c) {
@@ -125,28 +144,35 @@ __device__ inline float max3f(float a, float b, float c) {
 }
 
 // Wait until at most N of this wave's vector-memory operations (LDS-DMA stage loads) are still
-// in flight, then the workgroup barrier.  (__syncthreads() would drain them all: vmcnt(0).)
+// in flight and its LDS traffic has drained, then the workgroup barrier.  (__syncthreads() would
+// drain the stage loads too: vmcnt(0).)
 template <int N> __device__ inline void wait_vm_then_barrier() {
 	asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+constexpr int kF16Threads = 256;             // 4 waves; TWO workgroups are resident per CU
+constexpr int kF16Waves = kF16Threads / 64;
+constexpr int kF16TQ = 64 * kF16Waves;       // queries per workgroup
+constexpr int kF16TB = 64;                   // rows per tile (= per workgroup step)
 constexpr int kF16Prefetch = 2;              // tiles in flight ahead of the one being multiplied
 constexpr int kF16Bufs = kF16Prefetch + 1;   // LDS tile buffers
-constexpr int kF16QueueCap = 640;            // candidate queue entries in LDS
+constexpr int kF16WaveQueue = 88;            // candidate queue entries per wave, in LDS
 constexpr int kF16EntryBytes = 80;
+constexpr int kF16FlushEvery = 8;            // steps between looks at the queue fill
 template <int D> constexpr int gemm_f16_lds_bytes() {
-	// tiles + per-wave bn' slots + candidate queue + its counter
-	return kF16Bufs * (kGemmTB * D * 2 + 8 * 256) + kF16QueueCap * kF16EntryBytes + 16;
+	// tiles + per-wave bn' slots + per-wave candidate queues + theta' + queue fills
+	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) +
+	       kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 16;
 }
-static_assert(gemm_f16_lds_bytes<128>() <= 160 * 1024, "LDS budget");
+static_assert(gemm_f16_lds_bytes<128>() <= 80 * 1024, "two workgroups per CU");
 
-template <int D>
-__global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
+template <int D, bool SAMPLE>
+__global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
 	static_assert(D == 128 || D == 64, "built for d = 64, 128");
 	constexpr int ROWB = D * 2;      // bytes per fp16 row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
 	constexpr int KS = D / 16;       // MFMA k-steps; lane half h of k-step s holds chunk h*KS + s
-	constexpr int TILE_BYTES = kGemmTB * ROWB;
+	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;  // rows per 256-byte LDS bank row
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
 	constexpr int PF = kF16Prefetch, NBUF = kF16Bufs;
@@ -155,12 +181,35 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16P
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int wq = wave & 3;   // query group: queries [64 wq, 64 wq + 64) of the workgroup's 256
-	const int wh = wave >> 2;  // row half: rows [64 wh, 64 wh + 64) of each 128-row tile
 	const int h = lane >> 5, r31 = lane & 31;
 	const uint32_t qtile = blockIdx.x % p.n_qtiles;
 	const uint32_t chunk = blockIdx.x / p.n_qtiles;
-	const uint32_t q0 = qtile * kGemmBf16TQ + wq * 64;
+	const uint32_t wg_q0 = qtile * kF16TQ;
+	const uint32_t q0 = wg_q0 + wave * 64;  // this wave's 64 queries
+
+	const uint32_t t0 = chunk * p.tiles_per_block;
+	uint32_t t1 = t0 + p.tiles_per_block;
+	if (t1 > p.n_tiles_sel)
+		t1 = p.n_tiles_sel;
+	if (t0 >= t1)
+		return;  // (whole workgroup)
+	const unsigned long long clk0 = p.clk ? clock64() : 0, wall0 = p.clk ? wall_clock64() : 0;
+
+	// LDS map
+	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
+	struct QEntry {
+		float acc[16];
+		float bn;
+		uint32_t row;
+		uint32_t qrow0;  // query of accumulator register 0; register r is + (r & 3) + 8 (r >> 2)
+		uint32_t pad;
+	};
+	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
+	QEntry* const queue =
+	    reinterpret_cast<QEntry*>(bn_slots + NBUF * kF16Waves * 256) + wave * kF16WaveQueue;
+	float* const thq = reinterpret_cast<float*>(bn_slots + NBUF * kF16Waves * 256 +
+	                                            kF16Waves * kF16WaveQueue * kF16EntryBytes);
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + kF16TQ);
 
 	f16x8 a[2][KS];
 #pragma unroll
@@ -175,14 +224,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16P
 			a[tq][s] = src[h * KS + s];
 	}
 	// accumulator start values: theta' of the query each accumulator register belongs to
+	// (SAMPLE: they start at zero, and th holds the running class maxima of g instead)
 	f32x16 th[2];
 #pragma unroll
 	for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			th[tq][reg] = qi < p.m ? p.theta[qi] : -__builtin_inff();
+			th[tq][reg] = (qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff();
 		}
+	if (!SAMPLE)
+		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
 	// the query fragments and thresholds are in registers before the first stage load is issued:
 	// a later wait for them would be a vmcnt(0) inside the loop and drain the prefetch queue
 #pragma unroll
@@ -192,110 +244,89 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16P
 			asm volatile("" : "+v"(a[tq][s]));
 		asm volatile("" : "+v"(th[tq]));
 	}
-	// per-lane LDS offset of k-step s (row r31 of this wave's first column tile); the second
-	// column tile is 32 rows further, where the swizzle term is the same
+	// per-lane LDS offset of k-step s (row r31 of the first column tile); the second column tile
+	// is 32 rows further, where the swizzle term is the same
 	static_assert((32 / RPB) % (SWM + 1) == 0, "swizzle must repeat every 32 rows");
 	uint32_t aoff[KS];
 #pragma unroll
 	for (int s = 0; s < KS; ++s)
-		aoff[s] = (wh * 64 + r31) * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
+		aoff[s] = r31 * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
 
-	const uint32_t t0 = chunk * p.tiles_per_block;
-	uint32_t t1 = t0 + p.tiles_per_block;
-	if (t1 > p.n_tiles_sel)
-		t1 = p.n_tiles_sel;
-	if (t0 >= t1)
-		return;  // (whole workgroup)
 	auto tile_row0 = [&](uint32_t t) -> uint32_t {
-		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kGemmTB;
+		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kF16TB;
 	};
 
-	// Staging: every wave issues exactly N_STAGE + 1 LDS-DMA loads per tile (its share of the
-	// tile and the bn' of its own 64 rows into a private slot), so the vmcnt arithmetic below is
-	// the same for all waves.
-	constexpr int ROWS_PER_INSTR = kGemmThreads / CH;
+	// Staging: every wave issues N_STAGE + 1 LDS-DMA loads per tile (its share of the tile, and
+	// the bn' of the 64 rows into a slot of its own), every step, with no branches -- the last
+	// steps re-stage the final tile into a free buffer -- so the stage loads sit in the same
+	// basic block as the MFMAs and the vmcnt arithmetic is a constant.
+	constexpr int ROWS_PER_INSTR = kF16Threads / CH;
 	static_assert(ROWS_PER_INSTR % (16 * RPB) == 0, "swizzle must be instruction-invariant");
-	constexpr int N_STAGE = kGemmTB * CH / kGemmThreads;
+	constexpr int N_STAGE = kF16TB * CH / kF16Threads;
 	constexpr int LOADS = N_STAGE + 1;
 	const uint32_t lane_row = tid / CH;
 	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
-	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
 	auto stage = [&](uint32_t t, int buf) {
+		if (t > t1 - 1)
+			t = t1 - 1;
 		const uint32_t row0 = tile_row0(t);
 		unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
-		if (row0 + kGemmTB <= p.n_rows) {
-			const unsigned char* tb = (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB;
+		const unsigned char* tb = (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB + lane_off;
 #pragma unroll
-			for (int i = 0; i < N_STAGE; ++i)
-				__builtin_amdgcn_global_load_lds(
-				    (const __attribute__((address_space(1))) void*)(tb + lane_off +
-				                                                    (uint32_t)i * ROWS_PER_INSTR * ROWB),
-				    (__attribute__((address_space(3))) void*)(dst0 + i * kGemmThreads * 16), 16, 0, 0);
-		} else {
-#pragma unroll
-			for (int i = 0; i < N_STAGE; ++i) {
-				uint32_t grow = row0 + i * ROWS_PER_INSTR + lane_row;
-				if (grow >= p.n_rows)
-					grow = p.n_rows - 1;
-				const unsigned char* src = (const unsigned char*)p.base_f16 + (size_t)grow * ROWB +
-				                           (lane_off - lane_row * ROWB);
-				__builtin_amdgcn_global_load_lds(
-				    (const __attribute__((address_space(1))) void*)src,
-				    (__attribute__((address_space(3))) void*)(dst0 + i * kGemmThreads * 16), 16, 0, 0);
-			}
-		}
-		uint32_t brow = row0 + wh * 64 + lane;  // rows past the end: a copy of the last row's bn',
-		if (brow >= p.n_rows)                   // dropped again by the row check in the epilogue
-			brow = p.n_rows - 1;
+		for (int i = 0; i < N_STAGE; ++i)
+			__builtin_amdgcn_global_load_lds(
+			    (const __attribute__((address_space(1))) void*)(tb + (uint32_t)i * ROWS_PER_INSTR * ROWB),
+			    (__attribute__((address_space(3))) void*)(dst0 + i * kF16Threads * 16), 16, 0, 0);
 		__builtin_amdgcn_global_load_lds(
-		    (const __attribute__((address_space(1))) void*)(p.bnorm + brow),
-		    (__attribute__((address_space(3))) void*)(bn_slots + (buf * 8 + wave) * 256), 4, 0, 0);
+		    (const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
+		    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0, 0);
 	};
 	auto read_bn = [&](float (&bnv)[2], int buf) {
-		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * 8 + wave) * 256);
+		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * kF16Waves + wave) * 256);
 		bnv[0] = slot[r31];
 		bnv[1] = slot[32 + r31];
 	};
+
 	// Candidates: a lane whose 16 accumulators of a 32x32 tile hold at least one hit (about a
 	// third of all tiles do, at ~32k candidates per query) appends the raw 16-vector, its bn', row
-	// and first query to a queue in LDS -- one LDS atomic and five 16-byte stores, no per-register
-	// branches in the MFMA loop.  The workgroup empties the queue when it is half full and at the
-	// end: 16 threads per entry redo the compare and push the hits to the global per-query lists.
-	struct QEntry {
-		float acc[16];
-		float bn;
-		uint32_t row;
-		uint32_t qrow0;  // query of accumulator register 0; register r is + (r & 3) + 8 (r >> 2)
-		uint32_t pad;
-	};
-	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
-	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * 8 * 256);
-	uint32_t* const qcount = reinterpret_cast<uint32_t*>(queue + kF16QueueCap);
-	if (tid == 0)
-		*qcount = 0;  // (ordered before the first push by the barrier after the prologue stages)
+	// and first query to its WAVE's queue in LDS: the slot comes from a wave-uniform counter and
+	// the lane's rank in the ballot, so the hot loop has no atomic and no per-register branch.
+	// Every kF16FlushEvery steps the waves look at each other's fills and, if one is half full,
+	// each empties its own queue: 16 lanes per entry redo the compare and push the hits to the
+	// global per-query lists, a batch of atomics in flight at a time.
+	uint32_t wfill = 0;  // wave-uniform
 	auto push_global = [&](uint32_t qi, uint64_t key) {
 		const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
 		if (slot < p.cap)
 			p.cand[(size_t)qi * p.cap + slot] = key;
 	};
 	// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
-	auto flush = [&]() {  // whole workgroup, after a barrier
-		uint32_t n = *qcount;
-		if (n > (uint32_t)kF16QueueCap)
-			n = kF16QueueCap;
-		for (uint32_t i = tid; i < n * 16; i += kGemmThreads) {
-			const QEntry& e = queue[i >> 4];
-			const uint32_t reg = i & 15;
-			const float c = e.acc[reg], bn = e.bn;
-			if (c >= bn) {
-				const uint32_t qi = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
-				push_global(qi, make_key(((bn - c) + p.theta[qi]) * p.two_inv_s2, e.row));
+	auto flush_own = [&]() {
+		const uint32_t n = wfill < (uint32_t)kF16WaveQueue ? wfill : (uint32_t)kF16WaveQueue;
+		constexpr int R = 4;
+		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
+			bool hit[R];
+			uint32_t qi[R], slot[R];
+			uint64_t key[R];
+#pragma unroll
+			for (int j = 0; j < R; ++j) {
+				const uint32_t i = base + j * 64 + lane;
+				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
+				const uint32_t reg = i & 15;
+				const float c = e.acc[reg], bn = e.bn;
+				hit[j] = i < n * 16 && c >= bn;
+				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
+				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (kF16TQ - 1)]) * p.two_inv_s2, e.row);
 			}
+#pragma unroll
+			for (int j = 0; j < R; ++j)
+				slot[j] = hit[j] ? atomicAdd(&p.cand_cnt[qi[j]], 1u) : 0xFFFFFFFFu;
+#pragma unroll
+			for (int j = 0; j < R; ++j)
+				if (hit[j] && slot[j] < p.cap)
+					p.cand[(size_t)qi[j] * p.cap + slot[j]] = key[j];
 		}
-		wait_vm_then_barrier<0>();
-		if (tid == 0)
-			*qcount = 0;
-		wait_vm_then_barrier<0>();
+		wfill = 0;
 	};
 	auto epilogue = [&](const f32x16 (&accs)[2][2], uint32_t row0, const float (&bnv)[2]) {
 #pragma unroll
@@ -312,13 +343,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16P
 				m0 = max3f(m0, m1, c[15]);
 				m2 = max3f(m2, m3, m4);
 				m0 = __builtin_fmaxf(m0, m2);
-				if (__builtin_amdgcn_ballot_w64(m0 >= bn) != 0 && !(p.debug & 8)) {
+				const unsigned long long mask = __builtin_amdgcn_ballot_w64(m0 >= bn);
+				if (mask != 0 && !(p.debug & 8)) {
 					uint32_t qrow0 = q0 + tq * 32 + 4 * h;  // rare path: arithmetic stays in here
 					asm volatile("" : "+v"(qrow0));
-					const uint32_t brow = row0 + wh * 64 + tc * 32 + r31;
-					if (m0 >= bn && brow < p.n_rows) {
-						const uint32_t slot = atomicAdd(qcount, 1u);
-						if (slot < (uint32_t)kF16QueueCap) {
+					const uint32_t brow = row0 + tc * 32 + r31;
+					const uint32_t slot =
+					    wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+					                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+					if (m0 >= bn) {
+						if (slot < (uint32_t)kF16WaveQueue) {
 							QEntry& e = queue[slot];
 #pragma unroll
 							for (int reg = 0; reg < 16; ++reg)
@@ -340,86 +374,164 @@ __global__ __launch_bounds__(kGemmThreads, 2) void scan_gemm_f16_kernel(GemmF16P
 							}
 						}
 					}
+					wfill += (uint32_t)__builtin_popcountll(mask);
 				}
 			}
-	};
-	// before the barrier that ends step t: tile t+1 must have landed; the stages issued after
-	// it (tiles t+2 .. min(t+PF, t1-1)) may stay in flight
-	auto end_of_step = [&](uint32_t t) {
-		const uint32_t last = (t + PF < t1 - 1) ? t + PF : t1 - 1;
-		const uint32_t later = last > t + 1 ? last - (t + 1) : 0;
-		static_assert(PF == 2, "cases below");
-		if (later == 1)
-			wait_vm_then_barrier<1 * LOADS>();
-		else
-			wait_vm_then_barrier<0>();
 	};
 
 #pragma unroll
 	for (int i = 0; i < PF; ++i)
-		if (t0 + i < t1)
-			stage(t0 + i, i);
-	{  // tile t0 landed (same count as "end of step t0 - 1")
-		const uint32_t last = (t0 + PF - 1 < t1 - 1) ? t0 + PF - 1 : t1 - 1;
-		const uint32_t later = last - t0;
-		if (later == 1)
-			wait_vm_then_barrier<1 * LOADS>();
-		else
-			wait_vm_then_barrier<0>();
-	}
+		stage(t0 + i, i);
+	wait_vm_then_barrier<(PF - 1) * LOADS>();  // tile t0 landed, thq visible
 
-	// Waves w and w+4 share a SIMD (and the same queries): the upper four run their epilogue one
-	// step late, so that on each SIMD one wave's compares overlap the other's MFMAs.
-	const bool deferred = wave >= 4;
 	f32x16 acc[2][2];
-	uint32_t prev_row0 = 0;
-	bool have_prev = false;
+	f32x16 zero16;
+#pragma unroll
+	for (int e = 0; e < 16; ++e)
+		zero16[e] = 0.0f;
 	float bnv[2];
 	int buf = 0, pbuf = PF;  // pbuf: buffer that tile t+PF goes to (= the one tile t-1 used)
+	uint32_t since_look = 0;
 	for (uint32_t t = t0; t < t1; ++t) {
-		if (t + PF < t1 && !(p.debug & 1))
-			stage(t + PF, pbuf);
-		if (deferred && have_prev && !(p.debug & 4))
-			epilogue(acc, prev_row0, bnv);
 		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int tc, int s) -> f16x8 {
 			return *reinterpret_cast<const f16x8*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
 		};
-		if (p.debug & 2) {
-#pragma unroll
-			for (int tq = 0; tq < 2; ++tq)
-				acc[tq][0] = acc[tq][1] = th[tq];
-		} else
+		stage(t + PF, pbuf);
+		// fragments of k-step s+1 are requested before the MFMAs of k-step s issue
+		f16x8 b0 = frag(0, 0), b1 = frag(1, 0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
-			const f16x8 b0 = frag(0, s), b1 = frag(1, s);
+			f16x8 n0 = b0, n1 = b1;
+			if (s + 1 < KS) {
+				n0 = frag(0, s + 1);
+				n1 = frag(1, s + 1);
+			}
 #pragma unroll
 			for (int tq = 0; tq < 2; ++tq) {
-				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], b0,
-				                                                    s == 0 ? th[tq] : acc[tq][0], 0, 0, 0);
-				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], b1,
-				                                                    s == 0 ? th[tq] : acc[tq][1], 0, 0, 0);
+				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+				    a[tq][s], b0, s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
+				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+				    a[tq][s], b1, s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
 			}
+			b0 = n0;
+			b1 = n1;
+		}
+		// pin the order: 2 LDS reads, then per k-step {2 LDS reads, 4 MFMAs}
+		__builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+		for (int s = 0; s < KS; ++s) {
+			if (s + 1 < KS)
+				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 		}
 		read_bn(bnv, buf);
-		const uint32_t row0 = tile_row0(t);
-		if (!deferred) {
-			if (!(p.debug & 4))
-				epilogue(acc, row0, bnv);
+		if (SAMPLE) {
+			// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
+			// never wins a max
+#pragma unroll
+			for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+				for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+					for (int reg = 0; reg < 16; ++reg)
+						th[tq][reg] = __builtin_fmaxf(th[tq][reg], acc[tq][tc][reg] - bnv[tc]);
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
 		} else {
-			prev_row0 = row0;
-			have_prev = true;
+			if (!(p.debug & 4))
+				epilogue(acc, tile_row0(t), bnv);
+			const bool look = ++since_look == kF16FlushEvery;
+			if (look && lane == 0)
+				fills[wave] = wfill;
+			// tile t+1 must have landed; the stages of tiles t+2 .. t+PF may stay in flight
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
+			if (look) {
+				since_look = 0;
+				const uint32_t f = fills[lane & 3];
+				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)kF16WaveQueue / 2) != 0)
+					flush_own();
+			}
 		}
-		end_of_step(t);
-		if (*qcount >= (uint32_t)kF16QueueCap / 2)
-			flush();
 		pbuf = buf;
 		buf = buf + 1 == NBUF ? 0 : buf + 1;
 	}
-	if (deferred && have_prev && !(p.debug & 4))
-		epilogue(acc, prev_row0, bnv);
-	wait_vm_then_barrier<0>();
-	flush();
+	if (SAMPLE) {
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+			for (int reg = 0; reg < 16; ++reg) {
+				const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+				if (qi < p.m)
+					p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[tq][reg];
+			}
+	} else {
+		flush_own();
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tiles: LDS must outlive them
+	if (p.clk && blockIdx.x == 0 && tid == 0) {
+		p.clk[0] = clock64() - clk0;
+		p.clk[1] = wall_clock64() - wall0;
+	}
+}
+
+// tau[q] = an upper bound of the k-th smallest reference-order score over the sampled rows, from
+// the n_vals class maxima of g written by the SAMPLE pass.  The k largest maxima belong to k
+// different rows; for a row with g = q16.b16 - bn' the slack analysis at the top of this file
+// gives   score <= ||q||^2 (1+eps) - g/mul + 2 eps ||b||^2 + abs (|q| + 2|b|),   mul = s^2/2,
+// evaluated here with the largest ||b||^2 of the index.  One wave per query.
+struct SampleTauParams {
+	const float* vals;   // [m][n_vals]
+	uint32_t n_vals;
+	uint32_t m;
+	uint32_t k;
+	const float* qnrm;   // [m] ||q||^2
+	const float* bn_max; // [1] max ||b||^2
+	float eps, abs_coef, inv_mul;
+	float* tau;          // [m]
+	uint32_t* tau_row;   // [m] <- 0xFFFFFFFF (no row tie-break: the GEMM forms do not use it)
+};
+__global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (qi >= p.m)
+		return;  // (whole wave)
+	constexpr int PER = 32;  // values per lane at most (n_vals <= 2048)
+	const float* v = p.vals + (size_t)qi * p.n_vals;
+	uint64_t keys[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const uint32_t i = j * 64 + lane;
+		// larger g first: order by ~ordered(g); the index keeps equal values apart
+		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
+	}
+	uint64_t kth = 0;
+	for (uint32_t it = 0; it < p.k; ++it) {
+		uint64_t best = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			best = keys[j] > best ? keys[j] : best;
+		for (int off = 32; off > 0; off >>= 1) {
+			const uint64_t o = __shfl_xor(best, off);
+			best = o > best ? o : best;
+		}
+		kth = best;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			keys[j] = keys[j] == best ? 0ull : keys[j];
+	}
+	if (lane == 0) {
+		float tau = __builtin_inff();
+		if (kth != 0) {
+			const float g = ordered_to_float((uint32_t)(kth >> 32));
+			const float qn = p.qnrm[qi], bm = p.bn_max[0];
+			tau = qn * (1.0f + p.eps) - g * p.inv_mul + 2.0f * p.eps * bm +
+			      p.abs_coef * (__builtin_sqrtf(qn) + 2.0f * __builtin_sqrtf(bm));
+			if (!(tau == tau))
+				tau = __builtin_inff();
+		}
+		p.tau[qi] = tau;
+		p.tau_row[qi] = 0xFFFFFFFFu;
+	}
 }
 
 }  // namespace expann
