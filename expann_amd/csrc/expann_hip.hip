@@ -679,8 +679,9 @@ restart_direct:
 				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
 				tp.tau = h->d_tau[(li_start + 1) & 1];
 				tp.tau_row = h->d_tau_row[(li_start + 1) & 1];
-				hipLaunchKernelGGL(sample_tau_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
-				                   dim3(kBlock), 0, st, tp);
+				hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_kernel<8> : sample_tau_kernel<32>,
+				                   dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
+				                   tp);
 				HIP_TRY(h, hipGetLastError());
 			}
 		}

@@ -266,20 +266,32 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	constexpr int LOADS = N_STAGE + 1;
 	const uint32_t lane_row = tid / CH;
 	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
-	auto stage = [&](uint32_t t, int buf) {
-		if (t > t1 - 1)
-			t = t1 - 1;
-		const uint32_t row0 = tile_row0(t);
-		unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
-		const unsigned char* tb = (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB + lane_off;
-#pragma unroll
-		for (int i = 0; i < N_STAGE; ++i)
+	// piece i of a tile's stage: i < N_STAGE the wave's i-th 1 KiB of the tile, i == N_STAGE the bn'
+	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
+		if (i < N_STAGE) {
+			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
 			__builtin_amdgcn_global_load_lds(
 			    (const __attribute__((address_space(1))) void*)(tb + (uint32_t)i * ROWS_PER_INSTR * ROWB),
 			    (__attribute__((address_space(3))) void*)(dst0 + i * kF16Threads * 16), 16, 0, 0);
-		__builtin_amdgcn_global_load_lds(
-		    (const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
-		    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0, 0);
+		} else {
+			__builtin_amdgcn_global_load_lds(
+			    (const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
+			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0,
+			    0);
+		}
+	};
+	auto stage_src = [&](uint32_t t, uint32_t& row0) -> const unsigned char* {
+		if (t > t1 - 1)
+			t = t1 - 1;
+		row0 = tile_row0(t);
+		return (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB + lane_off;
+	};
+	auto stage = [&](uint32_t t, int buf) {
+		uint32_t row0;
+		const unsigned char* tb = stage_src(t, row0);
+#pragma unroll
+		for (int i = 0; i < LOADS; ++i)
+			stage_piece(tb, row0, buf, i);
 	};
 	auto read_bn = [&](float (&bnv)[2], int buf) {
 		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * kF16Waves + wave) * 256);
@@ -397,9 +409,14 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		auto frag = [&](int tc, int s) -> f16x8 {
 			return *reinterpret_cast<const f16x8*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
 		};
-		stage(t + PF, pbuf);
-		// fragments of k-step s+1 are requested before the MFMAs of k-step s issue
+		// Order pinned by scheduling barriers: the fragments of k-step s+1 are requested before
+		// the MFMAs of k-step s issue, and the stage loads of tile t+PF go out one per k-step,
+		// in the shadow of the MFMAs (an LDS-DMA issue costs 60-180 cycles of the wave's time).
+		uint32_t srow0;
+		const unsigned char* stb = stage_src(t + PF, srow0);
+		static_assert(LOADS <= KS, "one stage piece per k-step");
 		f16x8 b0 = frag(0, 0), b1 = frag(1, 0);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
 			f16x8 n0 = b0, n1 = b1;
@@ -414,16 +431,11 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
 				    a[tq][s], b1, s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
 			}
+			if (s < LOADS)
+				stage_piece(stb, srow0, pbuf, s);
 			b0 = n0;
 			b1 = n1;
-		}
-		// pin the order: 2 LDS reads, then per k-step {2 LDS reads, 4 MFMAs}
-		__builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-		for (int s = 0; s < KS; ++s) {
-			if (s + 1 < KS)
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-			__builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		read_bn(bnv, buf);
 		if (SAMPLE) {
@@ -490,12 +502,12 @@ struct SampleTauParams {
 	float* tau;          // [m]
 	uint32_t* tau_row;   // [m] <- 0xFFFFFFFF (no row tie-break: the GEMM forms do not use it)
 };
+template <int PER>  // values per lane: n_vals <= 64 * PER
 __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	if (qi >= p.m)
 		return;  // (whole wave)
-	constexpr int PER = 32;  // values per lane at most (n_vals <= 2048)
 	const float* v = p.vals + (size_t)qi * p.n_vals;
 	uint64_t keys[PER];
 #pragma unroll
