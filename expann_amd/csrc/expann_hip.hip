@@ -633,6 +633,7 @@ restart_direct:
 		// scan_gemm_f16.hpp) gives the threshold of the full scan -- no direct level-0 scan, no
 		// intermediate candidate lists and selects
 		size_t li_start = 0;
+		bool theta_ready = false;  // the sample pass also wrote theta' and zeroed the list counters
 		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
 			const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
 			const uint32_t run = 16;
@@ -679,6 +680,10 @@ restart_direct:
 				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
 				tp.tau = h->d_tau[(li_start + 1) & 1];
 				tp.tau_row = h->d_tau_row[(li_start + 1) & 1];
+				tp.theta = h->d_theta;
+				tp.mul = 0.5f * h->f16_scale * h->f16_scale;
+				tp.cand_cnt = h->d_cnt;
+				theta_ready = true;
 				hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_kernel<8> : sample_tau_kernel<32>,
 				                   dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
 				                   tp);
@@ -707,7 +712,7 @@ restart_direct:
 			uint32_t n_chunks = std::min(target_chunks, max_chunks);
 			sp.groups_per_block = (L.n_groups_sel + n_chunks - 1) / n_chunks;
 			n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
-			if (!first)
+			if (!first && !theta_ready)
 				HIP_TRY(h, hipMemsetAsync(h->d_cnt, 0, sizeof(uint32_t) * m, st));
 			const bool use_gemm = gv && !first;
 			const bool timed = last && h->profiling && h->ev_used < kEventPairs;
@@ -718,7 +723,9 @@ restart_direct:
 				// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
 				const float f16_abs = gvf ? std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
 				                          : 0.0f;
-				if (gvf)
+				if (gvf && theta_ready)
+					;
+				else if (gvf)
 					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
 					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
 					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau,
@@ -937,7 +944,7 @@ restart_direct:
 			SelectParams sel{};
 			sel.cand = h->d_cand;
 			sel.cand_cnt = first ? nullptr : h->d_cnt;
-			sel.fixed_count = L.n_groups_sel * kRowsPerGroup;
+			sel.fixed_count = (h->opt_debug & 256) ? 12345 : L.n_groups_sel * kRowsPerGroup;
 			sel.cap = cap;
 			sel.k = (uint32_t)k;
 			sel.id_offset = h->id_offset;
@@ -959,7 +966,15 @@ restart_direct:
 			                    : 0.0f;
 			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
 			sel.overflow = h->d_overflow;
-			sel.total_cand = last ? h->d_total : nullptr;
+			if (last && sel.cand_cnt && h->profiling)  // statistics: candidates of the full scan
+				hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
+				                   h->d_total);
+			if (sel.rerank_base && sel.cand_cnt && !(h->opt_debug & 512)) {
+				// short lists (the usual case after a GEMM-form scan): one wave per query
+				hipLaunchKernelGGL(select_wave_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
+				                   dim3(kBlock), 0, st, sel, (uint32_t)m);
+				sel.wave_done = 1;
+			}
 			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
 			                   sizeof(uint64_t) * cap + 16, st, sel);
 			HIP_TRY(h, hipGetLastError());

@@ -501,6 +501,9 @@ struct SampleTauParams {
 	float eps, abs_coef, inv_mul;
 	float* tau;          // [m]
 	uint32_t* tau_row;   // [m] <- 0xFFFFFFFF (no row tie-break: the GEMM forms do not use it)
+	float* theta;        // [m] <- (tau - (||q||^2 (1-eps) - abs |q|)) * mul, as f16_terms_kernel
+	float mul;
+	uint32_t* cand_cnt;  // [m] <- 0 (the full scan's list counters)
 };
 template <int PER>  // values per lane: n_vals <= 64 * PER
 __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
@@ -543,6 +546,9 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		}
 		p.tau[qi] = tau;
 		p.tau_row[qi] = 0xFFFFFFFFu;
+		const float qn = p.qnrm[qi];
+		p.theta[qi] = (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
+		p.cand_cnt[qi] = 0;
 	}
 }
 

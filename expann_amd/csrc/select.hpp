@@ -35,8 +35,293 @@ struct SelectParams {
 	float prune_abs;          // absolute slack coefficient (fp16 form): + prune_abs*(|q| + |b|max)
 	const float* bn_max;      // [1] max over rows of ||b||^2 (1-eps)
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
-	unsigned long long* total_cand;  // [1] sum of counts (statistics) or nullptr
+	uint32_t wave_done;       // select_wave_kernel already served the lists of <= kSelectWaveMax keys
 };
+
+// statistics: *out = sum of counts (one workgroup; one same-address atomic per query in the
+// select kernel would cost ~10 ns each, 100 us at 10^4 queries)
+__global__ __launch_bounds__(1024) void sum_u32_kernel(const uint32_t* in, uint32_t n,
+                                                       unsigned long long* out) {
+	__shared__ unsigned long long red[16];
+	unsigned long long s = 0;
+	for (uint32_t i = threadIdx.x; i < n; i += 1024)
+		s += in[i];
+	for (int off = 32; off > 0; off >>= 1)
+		s += __shfl_xor(s, off);
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 16; ++w)
+			s += red[w];
+		out[0] = s;
+	}
+}
+
+// Short candidate lists of the GEMM forms (<= kSelectSmallMax row numbers with approximate
+// scores): no sort.  Ranks come from counting (every thread compares its keys with all others
+// through LDS broadcasts), the survivors of the pruning cut are re-scored exactly in one batch
+// of independent row loads, and the exact keys are ranked by counting again.  Four barriers.
+constexpr uint32_t kSelectSmallMax = 512;
+
+__device__ inline void select_small(const SelectParams& p, uint64_t* keys, uint32_t c, uint32_t qi) {
+	const uint32_t tid = threadIdx.x;
+	// LDS: keys[512] | exact[512] | counters
+	uint64_t* exact = keys + kSelectSmallMax;
+	uint32_t* s_n = reinterpret_cast<uint32_t*>(exact + kSelectSmallMax);
+	float* s_cut = reinterpret_cast<float*>(s_n + 1);
+	const uint64_t* src = p.cand + (size_t)qi * p.cap;
+	const uint64_t k0 = tid < c ? src[tid] : kSentinelKey;
+	const uint64_t k1 = tid + kBlock < c ? src[tid + kBlock] : kSentinelKey;
+	keys[tid] = k0;
+	keys[tid + kBlock] = k1;
+	if (tid == 0) {
+		*s_n = 0;
+		*s_cut = __builtin_inff();
+	}
+	const uint32_t l = tid & 15, grp = tid >> 4;  // 16 lanes per candidate row
+	const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
+	const bool prune = p.prune_eps > 0.0f && !p.metric_ip && c > p.k;
+	__syncthreads();
+	if (prune) {
+		uint32_t r0 = 0, r1 = 0;
+		for (uint32_t j = 0; j < c; ++j) {
+			const uint64_t x = keys[j];
+			r0 += x < k0 ? 1u : 0u;
+			r1 += x < k1 ? 1u : 0u;
+		}
+		float qn = 0.0f;
+		for (uint32_t t = 0; t < p.dim / 16; ++t)
+			qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
+		qn = reduce16_ref_order(qn);
+		const float bmax = p.bn_max[0];
+		const float margin = p.prune_eps * (qn + 1.5f * bmax) +
+		                     p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
+		if (r0 == p.k - 1 && tid < c)
+			*s_cut = key_score(k0) + margin;
+		if (r1 == p.k - 1 && tid + kBlock < c)
+			*s_cut = key_score(k1) + margin;
+		__syncthreads();
+	}
+	{
+		const float cut = *s_cut;
+		if (tid < c && key_score(k0) <= cut)
+			exact[atomicAdd(s_n, 1u)] = k0;  // (the survivor list lives in exact[] until re-scored)
+		if (tid + kBlock < c && key_score(k1) <= cut)
+			exact[atomicAdd(s_n, 1u)] = k1;
+	}
+	__syncthreads();
+	const uint32_t n_s = *s_n;
+	// exact re-score (lane l owns dims l, l+16, ...; _mm512_reduce_add_ps tree): bit-identical to
+	// scan_filter_f32_kernel's scores (src/distance.h:136-147 / :181-190).  Four candidates per
+	// 16-lane group in flight.
+	for (uint32_t i0 = 0; i0 < n_s; i0 += 4 * (kBlock / 16)) {
+		float acc[4];
+		uint32_t row[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t i = i0 + u * (kBlock / 16) + grp;
+			row[u] = i < n_s ? key_idx(exact[i]) : key_idx(exact[0]);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const float* r = p.rerank_base + (size_t)row[u] * p.dim + l;
+			float a = 0.0f;
+			for (uint32_t t = 0; t < p.dim / 16; ++t) {
+				if (p.metric_ip) {
+					a = __builtin_fmaf(q[16 * t], r[16 * t], a);
+				} else {
+					const float diff = q[16 * t] - r[16 * t];
+					a = __builtin_fmaf(diff, diff, a);
+				}
+			}
+			acc[u] = reduce16_ref_order(a);
+		}
+		__syncthreads();  // every survivor of this batch has been read
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t i = i0 + u * (kBlock / 16) + grp;
+			if (l == 0 && i < n_s)
+				keys[i] = make_key(p.metric_ip ? -acc[u] : acc[u], row[u]);
+		}
+	}
+	__syncthreads();
+	// rank the exact keys by counting; rank r goes to output slot r
+	for (uint32_t i = tid; i < n_s; i += kBlock) {
+		const uint64_t mine = keys[i];
+		uint32_t r = 0;
+		for (uint32_t j = 0; j < n_s; ++j)
+			r += keys[j] < mine ? 1u : 0u;
+		if (r < p.k) {
+			if (p.out_ids)
+				p.out_ids[(size_t)qi * p.k + r] = (uint64_t)key_idx(mine) + p.id_offset;
+			if (p.out_dists)
+				p.out_dists[(size_t)qi * p.k + r] = key_score(mine);
+		}
+		if (r == p.k - 1 && p.tau_out) {
+			p.tau_out[qi] = key_score(mine);
+			if (p.tau_row_out)
+				p.tau_row_out[qi] = key_idx(mine);
+		}
+	}
+	for (uint32_t i = n_s + tid; i < p.k; i += kBlock) {  // fewer than k candidates: padding
+		if (p.out_ids)
+			p.out_ids[(size_t)qi * p.k + i] = ~0ull;
+		if (p.out_dists)
+			p.out_dists[(size_t)qi * p.k + i] = __builtin_inff();
+	}
+	if (tid == 0 && n_s < p.k && p.tau_out) {
+		p.tau_out[qi] = p.tau_prev ? p.tau_prev[qi] : __builtin_inff();
+		if (p.tau_row_out)
+			p.tau_row_out[qi] = p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu;
+	}
+}
+
+// min over the 64 lanes (result in every lane)
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+	// within rows of 16 by DPP rotations, then across the four rows
+	v = min(v, (uint32_t)row_ror_i<8>((int)v));
+	v = min(v, (uint32_t)row_ror_i<4>((int)v));
+	v = min(v, (uint32_t)row_ror_i<2>((int)v));
+	v = min(v, (uint32_t)row_ror_i<1>((int)v));
+	v = min(v, (uint32_t)__shfl_xor((int)v, 16));
+	v = min(v, (uint32_t)__shfl_xor((int)v, 32));
+	return v;
+}
+__device__ inline uint64_t wave_min_u64(uint64_t v) {
+	// the high word first (scores), the low word (rows) among the lanes that hold the min score
+	const uint32_t hi = (uint32_t)(v >> 32);
+	const uint32_t mhi = wave_min_u32(hi);
+	const uint32_t lo = hi == mhi ? (uint32_t)v : 0xFFFFFFFFu;
+	return ((uint64_t)mhi << 32) | wave_min_u32(lo);
+}
+
+// The same job as select_small, one WAVE per query (lists of <= kSelectWaveMax candidates of a
+// GEMM-form scan): the chain count -> keys -> candidate rows -> output is three dependent
+// memory round trips whatever the arithmetic, so the win is 4x the queries in flight and no
+// workgroup barriers.  Longer lists are left to select_topk_kernel (which skips the queries
+// done here when p.wave_done is set).
+constexpr uint32_t kSelectWaveMax = 512;
+
+__global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uint32_t m) {
+	__shared__ uint64_t lists[kBlock / 64][kSelectWaveMax];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t qi = blockIdx.x * (kBlock / 64) + wave;
+	if (qi >= m)
+		return;
+	const uint32_t c = p.cand_cnt[qi];
+	if (c > kSelectWaveMax)
+		return;
+	uint64_t* list = lists[wave];
+	const uint64_t* src = p.cand + (size_t)qi * p.cap;
+	constexpr int PER = kSelectWaveMax / 64;
+	uint64_t kk[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		kk[j] = lane + 64 * j < (int)c ? src[lane + 64 * j] : kSentinelKey;
+	const uint32_t l = lane & 15, grp = lane >> 4;  // 16 lanes per candidate row
+	const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
+	float cutoff = __builtin_inff();
+	if (p.prune_eps > 0.0f && !p.metric_ip && c > p.k) {
+		float qn = 0.0f;
+		for (uint32_t t = 0; t < p.dim / 16; ++t)
+			qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
+		qn = reduce16_ref_order(qn);
+		// k-th smallest approximate score (k-th DISTINCT one if scores repeat: a valid, looser cut)
+		uint32_t sc[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			sc[j] = (uint32_t)(kk[j] >> 32);
+		uint32_t kth = 0xFFFFFFFFu;
+		for (uint32_t r = 0; r < p.k; ++r) {
+			uint32_t mn = sc[0];
+#pragma unroll
+			for (int j = 1; j < PER; ++j)
+				mn = min(mn, sc[j]);
+			mn = wave_min_u32(mn);
+			if (mn == 0xFFFFFFFFu)
+				break;
+			kth = mn;
+#pragma unroll
+			for (int j = 0; j < PER; ++j)
+				sc[j] = sc[j] == mn ? 0xFFFFFFFFu : sc[j];
+		}
+		const float bmax = p.bn_max[0];
+		cutoff = ordered_to_float(kth) + p.prune_eps * (qn + 1.5f * bmax) +
+		         p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
+	}
+	uint32_t n_s = 0;  // wave-uniform
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const bool hit = lane + 64 * j < (int)c && key_score(kk[j]) <= cutoff;
+		const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+		const uint32_t pos = n_s + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+		                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+		if (hit)
+			list[pos] = kk[j];
+		n_s += (uint32_t)__builtin_popcountll(mask);
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS ops are in order)
+	// exact re-score, two candidates per 16-lane group in flight; slot i is read and rewritten
+	// by the one group that owns it
+	for (uint32_t i0 = 0; i0 < n_s; i0 += 8) {
+		float acc[2];
+		uint32_t row[2];
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const uint32_t i = i0 + 4 * u + grp;
+			row[u] = key_idx(list[i < n_s ? i : 0]);
+		}
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const float* r = p.rerank_base + (size_t)row[u] * p.dim + l;
+			float a = 0.0f;
+			for (uint32_t t = 0; t < p.dim / 16; ++t) {
+				if (p.metric_ip) {
+					a = __builtin_fmaf(q[16 * t], r[16 * t], a);
+				} else {
+					const float diff = q[16 * t] - r[16 * t];
+					a = __builtin_fmaf(diff, diff, a);
+				}
+			}
+			acc[u] = reduce16_ref_order(a);
+		}
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const uint32_t i = i0 + 4 * u + grp;
+			if (l == 0 && i < n_s)
+				list[i] = make_key(p.metric_ip ? -acc[u] : acc[u], row[u]);
+		}
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	uint64_t e[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		e[j] = lane + 64 * j < (int)n_s ? list[lane + 64 * j] : kSentinelKey;
+	for (uint32_t r = 0; r < p.k; ++r) {
+		uint64_t mn = e[0];
+#pragma unroll
+		for (int j = 1; j < PER; ++j)
+			mn = e[j] < mn ? e[j] : mn;
+		mn = wave_min_u64(mn);
+		const bool ok = mn != kSentinelKey;
+		if (lane == 0) {
+			if (p.out_ids)
+				p.out_ids[(size_t)qi * p.k + r] = ok ? (uint64_t)key_idx(mn) + p.id_offset : ~0ull;
+			if (p.out_dists)
+				p.out_dists[(size_t)qi * p.k + r] = ok ? key_score(mn) : __builtin_inff();
+			if (r == p.k - 1 && p.tau_out) {
+				p.tau_out[qi] = ok ? key_score(mn) : (p.tau_prev ? p.tau_prev[qi] : __builtin_inff());
+				if (p.tau_row_out)
+					p.tau_row_out[qi] = ok ? key_idx(mn) : (p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			e[j] = e[j] == mn ? kSentinelKey : e[j];
+	}
+}
 
 // One workgroup per query: bitonic sort of the (power-of-two padded) key list in LDS.
 __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
@@ -45,12 +330,16 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	const uint32_t qi = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	uint32_t c = p.cand_cnt ? p.cand_cnt[qi] : p.fixed_count;
-	if (tid == 0 && p.total_cand)
-		atomicAdd(p.total_cand, (unsigned long long)c);
+	if (p.wave_done && c <= kSelectWaveMax)
+		return;  // (uniform per workgroup)
 	if (c > p.cap) {
 		if (tid == 0)
 			atomicAdd(p.overflow, 1u);
 		c = p.cap;
+	}
+	if (p.rerank_base && c <= kSelectSmallMax && p.cap >= 2 * kSelectSmallMax + 2 && p.fixed_count != 12345) {
+		select_small(p, keys, c, qi);  // (uniform per workgroup)
+		return;
 	}
 	uint32_t n2 = 2;
 	while (n2 < c)
