@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-ratio", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--scan-kernel", type=int, default=0,
                     help="0 auto, 1 direct, 2 GEMM form fp32/int8 MFMA, 3 GEMM form bf16x3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -246,6 +247,8 @@ def main():
         eng.set_option("debug", a.debug)
     if a.sample_ratio:
         eng.set_option("sample_ratio", a.sample_ratio)
+    if a.sample_frac:
+        eng.set_option("sample_frac", a.sample_frac)
     ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
     dists = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
     out_ids = torch.empty_like(ids)

@@ -104,6 +104,7 @@ struct expann_index {
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
 	long opt_debug = 0;
+	long opt_sample_frac = 16;       // the sampled pass reads 1/opt_sample_frac of the rows
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
@@ -597,11 +598,11 @@ restart_direct:
 			h->q_split_bytes = nv * 4;
 		}
 		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end)
-		HIP_TRY(h, hipMemsetAsync(h->d_bnmax + 3, 0, sizeof(uint32_t), st));
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow + 2, 0, sizeof(uint32_t), st));
 		hipLaunchKernelGGL(convert_f16_kernel,
 		                   dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->f16_scale,
-		                   (_Float16*)h->d_q_split, (uint32_t*)(h->d_bnmax + 3));
+		                   (_Float16*)h->d_q_split, h->d_overflow + 2);
 		hipLaunchKernelGGL(gvf->sqnorm, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m, h->d_qnrm);
 		HIP_TRY(h, hipGetLastError());
@@ -637,9 +638,9 @@ restart_direct:
 		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
 			const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
 			const uint32_t run = 16;
-			uint32_t t_sel = std::max<uint32_t>(256, nt / 16) / run * run;
+			uint32_t t_sel = std::max<uint32_t>(256, nt / (uint32_t)h->opt_sample_frac) / run * run;
 			const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-			uint32_t chunks = std::max<uint32_t>(1, (2 * (uint32_t)cus) / nqt);
+			uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
 			chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 			chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
 			if (t_sel * 2 <= nt && (size_t)chunks * 32 >= 8 * k) {
@@ -744,7 +745,7 @@ restart_direct:
 				gp.n_tiles_sel = last ? n_tiles
 				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
 				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				const uint32_t tq_wg = (gvb || gvf) ? kGemmBf16TQ : kGemmTQ;
+				const uint32_t tq_wg = gvf ? (uint32_t)kF16TQ : (gvb ? kGemmBf16TQ : kGemmTQ);
 				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
 				gp.queries = (const float*)d_queries;
 				gp.theta = h->d_theta;
@@ -792,7 +793,7 @@ restart_direct:
 					fp.n_qtiles = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
 					uint32_t fchunks = 1;
 					{
-						const uint32_t slots = 2 * (uint32_t)cus;
+						const uint32_t slots = kF16WgPerCu * (uint32_t)cus;
 						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
 						double best = 1e300;
 						for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
@@ -828,6 +829,12 @@ restart_direct:
 					kname = gvf->name;
 					gp.n_qtiles = fp.n_qtiles;
 					if (fp.clk) {
+						int occ = -1;
+						hipOccupancyMaxActiveBlocksPerMultiprocessor(
+						    &occ, (const void*)gvf->scan, kF16Threads,
+						    h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>());
+						std::fprintf(stderr, "scan_gemm_f16: %d workgroups per CU resident, grid %u\n", occ,
+						             fchunks * fp.n_qtiles);
 						unsigned long long c[18] = {0};
 						HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
 						std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
@@ -989,8 +996,8 @@ restart_direct:
 		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
 		h->prof.candidates = tot;
 		if (gvf) {  // queries outside the fp16 range of this index: redo with the bf16x3 form
-			float qmax = 0.0f;
-			HIP_TRY(h, hipMemcpy(&qmax, h->d_bnmax + 3, sizeof(float), hipMemcpyDeviceToHost));
+			float qmax;  // bit pattern of max |q| (flags word 2, read back with the overflow flags)
+			std::memcpy(&qmax, &h->h_flags[2], sizeof(float));
 			if (!(qmax * h->f16_scale <= 60000.0f)) {
 				no_f16 = true;
 				h->prof.retries++;
@@ -1915,6 +1922,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_scan_kernel = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
+	else if (!std::strcmp(name, "sample_frac"))
+		h->opt_sample_frac = value < 2 ? 2 : value;
 	else if (!std::strcmp(name, "sample_ratio"))
 		h->opt_sample_ratio = value < 2 ? 2 : value;
 	else

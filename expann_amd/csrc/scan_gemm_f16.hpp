@@ -150,7 +150,11 @@ template <int N> __device__ inline void wait_vm_then_barrier() {
 	asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-constexpr int kF16Threads = 256;             // 4 waves; TWO workgroups are resident per CU
+#ifndef EXPANN_F16_THREADS
+#define EXPANN_F16_THREADS 256
+#endif
+constexpr int kF16Threads = EXPANN_F16_THREADS;  // 256: two workgroups per CU; 512: one
+constexpr int kF16WgPerCu = 512 / kF16Threads;
 constexpr int kF16Waves = kF16Threads / 64;
 constexpr int kF16TQ = 64 * kF16Waves;       // queries per workgroup
 constexpr int kF16TB = 64;                   // rows per tile (= per workgroup step)
@@ -164,7 +168,7 @@ template <int D> constexpr int gemm_f16_lds_bytes() {
 	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) +
 	       kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 16;
 }
-static_assert(gemm_f16_lds_bytes<128>() <= 80 * 1024, "two workgroups per CU");
+static_assert(gemm_f16_lds_bytes<128>() * kF16WgPerCu <= 160 * 1024, "LDS budget per CU");
 
 template <int D, bool SAMPLE>
 __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
@@ -409,35 +413,41 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		auto frag = [&](int tc, int s) -> f16x8 {
 			return *reinterpret_cast<const f16x8*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
 		};
-		// Order pinned by scheduling barriers: the fragments of k-step s+1 are requested before
+		// Order pinned by scheduling barriers: the fragments of k-step s+2 are requested before
 		// the MFMAs of k-step s issue, and the stage loads of tile t+PF go out one per k-step,
 		// in the shadow of the MFMAs (an LDS-DMA issue costs 60-180 cycles of the wave's time).
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
 		static_assert(LOADS <= KS, "one stage piece per k-step");
-		f16x8 b0 = frag(0, 0), b1 = frag(1, 0);
+		f16x8 fb[KS][2];
+		fb[0][0] = frag(0, 0);
+		fb[0][1] = frag(1, 0);
+		fb[1][0] = frag(0, 1);
+		fb[1][1] = frag(1, 1);
+		read_bn(bnv, buf);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
-			f16x8 n0 = b0, n1 = b1;
-			if (s + 1 < KS) {
-				n0 = frag(0, s + 1);
-				n1 = frag(1, s + 1);
+			if (s + 2 < KS) {  // two k-steps ahead: a wait for k-step s+1 never meets a fresh request
+				if (p.debug & 32) {
+					fb[s + 2][0] = fb[0][0];
+					fb[s + 2][1] = fb[0][1];
+				} else {
+					fb[s + 2][0] = frag(0, s + 2);
+					fb[s + 2][1] = frag(1, s + 2);
+				}
 			}
 #pragma unroll
 			for (int tq = 0; tq < 2; ++tq) {
 				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-				    a[tq][s], b0, s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
+				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
 				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-				    a[tq][s], b1, s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
+				    a[tq][s], fb[s][1], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
 			}
-			if (s < LOADS)
+			if (s < LOADS && !(p.debug & 2))
 				stage_piece(stb, srow0, pbuf, s);
-			b0 = n0;
-			b1 = n1;
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		read_bn(bnv, buf);
 		if (SAMPLE) {
 			// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
 			// never wins a max
@@ -456,10 +466,11 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 			if (look && lane == 0)
 				fills[wave] = wfill;
 			// tile t+1 must have landed; the stages of tiles t+2 .. t+PF may stay in flight
-			wait_vm_then_barrier<(PF - 1) * LOADS>();
+			if (!(p.debug & 1))
+				wait_vm_then_barrier<(PF - 1) * LOADS>();
 			if (look) {
 				since_look = 0;
-				const uint32_t f = fills[lane & 3];
+				const uint32_t f = fills[lane & (kF16Waves - 1)];
 				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)kF16WaveQueue / 2) != 0)
 					flush_own();
 			}
