@@ -358,9 +358,9 @@ struct GemmF16Variant {
 	const char* name;
 };
 const GemmF16Variant kGemmF16[] = {
-    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>, "scan_gemm_f16<64>"},
+    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>, "scan_gemm_f16<64, false>"},
     {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
-     "scan_gemm_f16<128>"}};
+     "scan_gemm_f16<128, false>"}};
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
