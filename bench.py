@@ -4,8 +4,11 @@
 A "step" is one pass of the hot path over one batch: the brute-force k-NN search of M
 queries against the N-row fp32 base (config C2: N=1M, d=128, M=10k, k=10, L2), inputs
 resident in HBM.  With --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) the
-base is sharded by contiguous row ranges (strong scaling: total N fixed), every rank scans
-its shard for all queries, the per-shard top-k are all-gathered over RCCL and merged.
+base is sharded by contiguous row ranges (strong scaling: total N and total queries fixed).
+Default rank grid: 2 row shards x (N/2) query groups (expann_amd/sharded.py): every rank scans
+its rows for its query slice, the per-shard top-k are all-gathered over RCCL inside the query
+group and merged, and the merged slices are all-gathered so that every rank holds the full
+result.  --row-shards N gives pure row sharding.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
 kernel, timed with HIP events on its stream inside the library) and `cpu_baseline` (the CPU
@@ -44,7 +47,13 @@ def parse():
                          "c4 = configs[3] graph search recall sweep (SIFT-like stand-in, "
                          "--n rows, built on the host CPU first)")
     ap.add_argument("--query-tile", type=int, default=0)
+    ap.add_argument("--row-shards", type=int, default=0,
+                    help="row shards of the rank grid (default: 2 when --gpus is even, queries split "
+                         "over the remaining factor; --row-shards N = pure row sharding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed loop rank 0 checks the sharded result bit for bit against an "
+                         "unsharded search of the whole base (f32 only)")
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-ratio", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
@@ -210,7 +219,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("EXPANN_BENCH_REHEARSAL"):
+            # rehearsal of the rank grid on a box with fewer GPUs than ranks: gloo, ranks share GPUs
+            local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     G = world
     torch.cuda.set_device(local_rank)
@@ -218,10 +232,14 @@ def main():
     from expann_amd import GpuBruteForceEngine, merge_topk_device
 
     # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
-    from expann_amd.sharded import shard_range
-    lo, hi = shard_range(a.n, rank, G)
+    from expann_amd.sharded import shard_range, shard_grid
+    R, Q = shard_grid(G, a.row_shards or None)       # rank = query group x row shard
+    row_idx, qgroup = rank % R, rank // R
+    lo, hi = shard_range(a.n, row_idx, R)
+    q_lo, q_hi = shard_range(a.m, qgroup, Q)
+    m_local, pad = q_hi - q_lo, (a.m + Q - 1) // Q
     g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
+    g.manual_seed(1234 + row_idx)
     if a.dtype == "f32":
         base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
         g.manual_seed(4321)
@@ -249,11 +267,11 @@ def main():
         eng.set_option("sample_ratio", a.sample_ratio)
     if a.sample_frac:
         eng.set_option("sample_frac", a.sample_frac)
-    ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
-    dists = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
+    ids = torch.full((pad, a.k), -1, dtype=torch.int64, device=dev)      # rows past the slice stay
+    dists = torch.full((pad, a.k), float("inf"), dtype=torch.float32, device=dev)  # padding
     out_ids = torch.empty_like(ids)
     out_d = torch.empty_like(dists)
-    gather_bufs = {}
+    bufs = {}
     stream = torch.cuda.current_stream().cuda_stream
 
     def local_search(q, k):
@@ -261,19 +279,17 @@ def main():
         return ids, dists
 
     def merge(all_ids, all_d):
-        merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), G, a.m, a.k,
+        merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), all_ids.shape[0], pad, a.k,
                           out_ids.data_ptr(), out_d.data_ptr(), stream)
         return out_ids, out_d
 
-    def alloc_gather(t):
-        key = t.dtype
-        if key not in gather_bufs:
-            gather_bufs[key] = torch.empty((G * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                                           device=dev)
-        return gather_bufs[key]
+    def alloc(name, shape, like):
+        if name not in bufs:
+            bufs[name] = torch.empty(shape, dtype=like.dtype, device=dev)
+        return bufs[name]
 
-    from expann_amd.sharded import ShardedSearch
-    ss = ShardedSearch(dist if G > 1 else None, G, local_search, merge, alloc_gather)
+    from expann_amd.sharded import GridShardedSearch
+    ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
 
     def step():
         ss.search(queries, a.k)
@@ -297,6 +313,29 @@ def main():
         elapsed = float(t.item())
     prof = eng.get_profile()
     eng.set_profiling(False)
+    if a.verify and a.dtype == "f32":
+        got_ids, got_d = ss.search(queries, a.k)
+        torch.cuda.synchronize()
+        if rank == 0:
+            parts = []
+            for r in range(R):
+                r_lo, r_hi = shard_range(a.n, r, R)
+                g.manual_seed(1234 + r)
+                parts.append(torch.randn(r_hi - r_lo, a.d, device=dev, dtype=torch.float32, generator=g))
+            whole = torch.cat(parts, 0)
+            ref = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
+            ref.set_base_device(whole.data_ptr(), a.n, 0)
+            ref_ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
+            ref_d = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
+            ref.search_device(queries.data_ptr(), a.m, a.k, ref_ids.data_ptr(), ref_d.data_ptr(), stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(got_ids[:a.m], ref_ids)) and \
+                bool(torch.equal(got_d[:a.m].view(torch.int32), ref_d.view(torch.int32)))
+            print(f"verify: sharded rows/{R} x queries/{Q} result "
+                  f"{'IDENTICAL to' if same else 'DIFFERS from'} the unsharded search", file=sys.stderr)
+            ref.close()
+            if not same:
+                sys.exit(3)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / a.steps
@@ -315,14 +354,14 @@ def main():
                     "single_pass_equiv_GBps": round(n_local * a.d * esz / (scan_ms * 1e-3) / 1e9, 2)
                     if scan_ms > 0 else 0.0}
         if prof["scan_kernel"].startswith("scan_gemm_i8"):
-            ops = 2.0 * n_local * a.d * a.m             # C5 2*N*d*m int ops
+            ops = 2.0 * n_local * a.d * m_local             # C5 2*N*d*m int ops
             tops = ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS,
                         "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
         elif prof["scan_kernel"].startswith("scan_gemm_f16"):
             # one fp16 MFMA product per fp32 product (scaled operands, rigorous slack, exact
             # re-rank): executed flops = algorithmic 2*N*d*m, priced against the dense fp16 peak
-            alg = 2.0 * n_local * a.d * a.m
+            alg = 2.0 * n_local * a.d * m_local
             tf = alg / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -331,7 +370,7 @@ def main():
         elif prof["scan_kernel"].startswith("scan_gemm_bf16x3"):
             # fp32 products evaluated exactly enough on the bf16 cores as 3 bf16 MFMA products
             # (hi*hi + hi*lo + lo*hi): executed flops = 3 x the algorithmic 2*N*d*m
-            alg = 2.0 * n_local * a.d * a.m
+            alg = 2.0 * n_local * a.d * m_local
             tf_alg = alg / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(3 * tf_alg, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(3 * tf_alg / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -341,7 +380,7 @@ def main():
                         "algorithmic_vs_fp32_mfma_peak": round(tf_alg / MFMA_F32_PEAK_TFLOPS, 3)}
         elif prof["scan_kernel"].startswith("scan_gemm"):
             # GEMM-form filter on the matrix cores: algorithmic flops = 2*N*d*m
-            flops = 2.0 * n_local * a.d * a.m
+            flops = 2.0 * n_local * a.d * m_local
             tf = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
@@ -354,7 +393,7 @@ def main():
             "traffic_source": traffic_src, "kernel": prof["scan_kernel"],
             "kernel_ms": round(scan_ms, 4), "launches": int(launches),
             "algorithmic_bytes_per_launch": alg_bytes, "hbm_view": hbm_view,
-            "candidates_per_query": round(prof["candidates"] / a.m, 1)})
+            "candidates_per_query": round(prof["candidates"] / m_local, 1)})
         desc = {"f32": "fp32", "i8": "int8", "u8": "uint8"}[a.dtype]
         shape = f"{a.n // 1_000_000}M" if a.n % 1_000_000 == 0 else str(a.n)
         out = {"metric": f"queries/sec at recall@{a.k}=1.0 (exact brute force), {shape}xd{a.d} {desc}, k={a.k}",
@@ -365,7 +404,9 @@ def main():
                                       f"{a.m} batched queries, k={a.k} (BASELINE "
                                       f"{'configs[1]' if a.workload == 'c2' else 'configs[4]'})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
-                          "sharding": f"rows/{G}" if G > 1 else "none"},
+                          "sharding": (f"rows/{R} x queries/{Q} (rank 0 scans {n_local} rows for {m_local} "
+                                       f"queries; roofline figures are rank 0's launch)")
+                          if G > 1 else "none"},
                "roofline": roofline}
         if G == 1 and not a.no_cpu_baseline:
             try:

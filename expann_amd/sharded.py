@@ -1,4 +1,5 @@
-"""Row-sharded brute force across the GPUs of one node (one process per GPU).
+"""Sharded brute force across the GPUs of one node (one process per GPU): `ShardedSearch` cuts
+the base into row shards; `GridShardedSearch` cuts rows x queries (the default of bench.py).
 
 The base set is cut into contiguous row ranges: rank r owns rows
 [r*n/G, (r+1)*n/G).  Every rank scans its shard for all queries (no data-path collective),
@@ -39,3 +40,77 @@ class ShardedSearch:
         self.dist.all_gather_into_tensor(all_d, dists)
         G = self.world
         return self.merge(all_ids.view(G, *ids.shape), all_d.view(G, *dists.shape))
+
+
+def shard_grid(world, row_shards=None):
+    """(row_shards, query_groups) of a `world`-rank job.  The base is always sharded when there is
+    more than one rank; by default into TWO row shards, the remaining factor splits
+    the queries: per-query costs (conversion, threshold pass, selection, result exchange) then
+    shrink with the group count instead of being repeated on every rank, and the all-gather of
+    per-shard top-k runs between 2 ranks.  `row_shards` = world reproduces pure row sharding."""
+    if row_shards is None:
+        row_shards = 2 if world % 2 == 0 else world
+    if world % row_shards:
+        raise ValueError(f"row_shards {row_shards} does not divide world {world}")
+    return row_shards, world // row_shards
+
+
+class GridShardedSearch:
+    """rank r = query group (r // R) x row shard (r % R), R = row shards.
+
+    search(): (1) every rank scans ITS rows for ITS query slice (no collective), (2) the R ranks
+    of a query group all-gather their [m_slice][k] lists and merge them (as ShardedSearch),
+    (3) the merged slices are all-gathered across the query groups, so every rank ends with the
+    full [m][k] result.  Slices are padded to ceil(m / groups) queries for the fixed-size
+    collectives."""
+
+    def __init__(self, dist, world, rank, row_shards, local_search, merge, alloc):
+        """local_search(queries_slice, k) -> (ids[ms,k], dists[ms,k]) of this rank's rows
+        (global ids), written into buffers with room for `pad` rows; merge(all_ids[R,ms,k],
+        all_d[R,ms,k]) -> (ids[ms,k], dists[ms,k]); alloc(name, shape, like) -> cached tensor."""
+        self.dist, self.world, self.rank = dist, world, rank
+        self.R, self.Q = shard_grid(world, row_shards)
+        self.row_idx, self.qgroup = rank % self.R, rank // self.R
+        self.local_search, self.merge, self.alloc = local_search, merge, alloc
+        self.row_group = self.col_group = None
+        if dist is not None and world > 1:
+            # every rank creates every group, in the same order (torch.distributed contract)
+            for g in range(self.Q):
+                grp = dist.new_group([g * self.R + i for i in range(self.R)]) if self.R > 1 else None
+                if g == self.qgroup:
+                    self.row_group = grp
+            for i in range(self.R):
+                grp = dist.new_group([g * self.R + i for g in range(self.Q)]) if self.Q > 1 else None
+                if i == self.row_idx:
+                    self.col_group = grp
+
+    def query_slice(self, m):
+        return shard_range(m, self.qgroup, self.Q)
+
+    def search(self, queries, k):
+        m = queries.shape[0]
+        lo, hi = self.query_slice(m)
+        pad = (m + self.Q - 1) // self.Q
+        ids, dists = self.local_search(queries[lo:hi], k)
+        if self.world == 1:
+            return ids, dists
+        if self.R > 1:
+            all_ids = self.alloc("row_ids", (self.R * ids.shape[0],) + tuple(ids.shape[1:]), ids)
+            all_d = self.alloc("row_d", (self.R * dists.shape[0],) + tuple(dists.shape[1:]), dists)
+            self.dist.all_gather_into_tensor(all_ids, ids, group=self.row_group)
+            self.dist.all_gather_into_tensor(all_d, dists, group=self.row_group)
+            ids, dists = self.merge(all_ids.view(self.R, *ids.shape), all_d.view(self.R, *dists.shape))
+        if self.Q == 1:
+            return ids[:m], dists[:m]
+        assert ids.shape[0] == pad, "local_search / merge must return the padded slice"
+        full_ids = self.alloc("full_ids", (self.Q * pad,) + tuple(ids.shape[1:]), ids)
+        full_d = self.alloc("full_d", (self.Q * pad,) + tuple(dists.shape[1:]), dists)
+        self.dist.all_gather_into_tensor(full_ids, ids, group=self.col_group)
+        self.dist.all_gather_into_tensor(full_d, dists, group=self.col_group)
+        if m == self.Q * pad:
+            return full_ids, full_d
+        import torch
+        parts = [shard_range(m, g, self.Q) for g in range(self.Q)]
+        keep_i = [full_ids[g * pad:g * pad + (b - a)] for g, (a, b) in enumerate(parts)]
+        keep_d = [full_d[g * pad:g * pad + (b - a)] for g, (a, b) in enumerate(parts)]
+        return torch.cat(keep_i, 0), torch.cat(keep_d, 0)

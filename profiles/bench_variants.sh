@@ -1,0 +1,13 @@
+#!/bin/bash
+# secondary configurations next to the default C2 line (one JSON line each, abbreviated)
+run() { timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import sys,json
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
+print(' '.join(sys.argv[1:]), '| QPS', j['value'], 'ms/step', j['ms_per_step'], 'scan_ms', r['kernel_ms'], r['kernel'], 'frac', r['frac'], 'cands', r['candidates_per_query'])" "$@"; }
+run --n 1250000 --k 100 --steps 5
+run --n 10000000 --k 100 --steps 3
+run --n 1000000 --k 10 --m 1000 --steps 20
+run --n 1000000 --k 10 --m 256 --steps 20
+run --n 1000000 --d 64 --k 10 --steps 10
+run --n 1000000 --dtype u8 --steps 10
+run --workload c5 --steps 3

@@ -70,6 +70,85 @@ def _worker(rank, world, port, n, d, m, k, out):
     dist.destroy_process_group()
 
 
+def _grid_worker(rank, world, row_shards, port, n, d, m, k, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import oracle_ctypes as oc
+    from expann_amd.sharded import GridShardedSearch, shard_range, shard_grid
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(78)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base[n // 3] = base[2 * n // 3]          # a cross-shard exact tie
+    queries = rng.standard_normal((m, d)).astype(np.float32)
+    queries[0] = base[n // 3]
+    R, Q = shard_grid(world, row_shards)
+    lo, hi = shard_range(n, rank % R, R)
+    pad = (m + Q - 1) // Q
+    bufs = {}
+
+    def alloc(name, shape, like):
+        if name not in bufs:
+            bufs[name] = torch.empty(shape, dtype=like.dtype)
+        return bufs[name]
+
+    def local_search(q, kk):
+        ids = np.full((pad, kk), np.uint64(2 ** 64 - 1), np.uint64)
+        dd = np.full((pad, kk), np.inf, np.float32)
+        i, x = oc.brute_force(base[lo:hi], q.numpy(), kk)
+        ids[:len(i)] = np.where(i == np.uint64(2 ** 64 - 1), i, i + np.uint64(lo))
+        dd[:len(i)] = x
+        return torch.from_numpy(ids.view(np.int64)), torch.from_numpy(dd)
+
+    def merge(all_ids, all_d):
+        i, dd = _merge_np(all_ids.numpy(), all_d.numpy())
+        return torch.from_numpy(i), torch.from_numpy(dd)
+
+    gs = GridShardedSearch(dist, world, rank, row_shards, local_search, merge, alloc)
+    ids, dd = gs.search(torch.from_numpy(queries), k)
+    ref_ids, ref_d = oc.brute_force(base, queries, k)
+    ok = ids.shape[0] == m and np.array_equal(ids.numpy().view(np.uint64), ref_ids) and \
+        np.array_equal(dd.numpy(), ref_d)
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,row_shards,m", [(4, None, 10), (4, 4, 9), (2, None, 7), (6, 2, 10),
+                                                (3, None, 5)])
+def test_grid_sharded_search_matches_unsharded(world, row_shards, m):
+    """rows x queries grid (bench.py's default layout): every rank must end with the full,
+    unsharded answer, ragged query slices included."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, row_shards, port, 2003, 64, m, 10, out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(out.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_shard_grid_defaults():
+    from expann_amd.sharded import shard_grid
+    assert shard_grid(1) == (1, 1)
+    assert shard_grid(2) == (2, 1)
+    assert shard_grid(4) == (2, 2)
+    assert shard_grid(8) == (2, 4)
+    assert shard_grid(3) == (3, 1)
+    assert shard_grid(8, 8) == (8, 1)
+    with pytest.raises(ValueError):
+        shard_grid(8, 3)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_search_matches_unsharded(world):
     import torch.multiprocessing as mp
