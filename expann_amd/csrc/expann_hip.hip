@@ -22,6 +22,7 @@
 #include "scan_gemm_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
+#include "scan_gemm_i8q.hpp"
 #include "scan_int8.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
@@ -85,7 +86,10 @@ struct expann_index {
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
 	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
 	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
-	float* d_sample = nullptr;       // [m][n_chunks][32] class maxima of the fp16 sample pass
+	void* d_base_i8q = nullptr;      // padded int8 copy of an 8-bit index (uint8 rows ^ 0x80) or alias of d_base
+	bool base_i8q_owned = false;
+	int* d_bp_i8q = nullptr;         // [n padded] floor(bias/2), scan_gemm_i8q.hpp
+	float* d_sample = nullptr;       // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
 	size_t sample_bytes = 0;
 	void* d_q_split = nullptr;       // [m][2][dim] bf16 (or [m][dim] fp16)
 	size_t q_split_bytes = 0;
@@ -491,6 +495,245 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 	return EXPANN_OK;
 }
 
+// ---- 8-bit GEMM form, queue geometry (scan_gemm_i8q.hpp), d = 128 / 256 ----------------------
+using GemmI8qFn = void (*)(GemmI8qParams);
+struct GemmI8qVariant {
+	int d, mode;
+	GemmI8qFn scan, sample;
+	SelfI8Fn self;
+	ThetaI8Fn theta;
+	const char* name;
+};
+#define GEMM_I8Q(D, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<D, L2F, false>, \
+	scan_gemm_i8q_kernel<D, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+	"scan_gemm_i8q<" #D "," MN ">"}
+const GemmI8qVariant kGemmI8q[] = {
+    GEMM_I8Q(128, kU8L2, true, "U8L2"), GEMM_I8Q(128, kI8L2, true, "I8L2"), GEMM_I8Q(128, kI8IP, false, "I8IP"),
+    GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP")};
+#undef GEMM_I8Q
+constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
+
+const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
+	if (h->dtype == EXPANN_DTYPE_F32 || !(h->opt_scan_kernel == 0 || h->opt_scan_kernel == 5))
+		return nullptr;
+	if (h->opt_scan_kernel == 0 && (m < 96 || h->n < 65536))
+		return nullptr;
+	if (h->n < 2 * 256 * kF16TB || k > 256)
+		return nullptr;
+	for (const auto& v : kGemmI8q)
+		if (v.d == h->dim && v.mode == h->int_mode)
+			return &v;
+	return nullptr;
+}
+
+int ensure_i8q(expann_index* h, const GemmI8qVariant* gq, hipStream_t st) {
+	if (h->d_base_i8q)
+		return EXPANN_OK;
+	const size_t n_pad = (h->n + kF16TB - 1) / kF16TB * kF16TB;
+	if (h->int_mode != kI8IP && !h->d_bias_i) {
+		HIP_TRY(h, hipMalloc(&h->d_bias_i, sizeof(int) * h->n));
+		hipLaunchKernelGGL(gq->self, dim3((uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup)),
+		                   dim3(kBlock), 0, st, (const void*)h->d_base, (uint32_t)h->n, h->d_bias_i);
+	}
+	HIP_TRY(h, hipMalloc(&h->d_bp_i8q, sizeof(int) * n_pad));
+	hipLaunchKernelGGL(i8q_bp_kernel, dim3((uint32_t)((n_pad + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+	                   st, h->int_mode != kI8IP ? (const int*)h->d_bias_i : (const int*)nullptr,
+	                   (uint32_t)h->n, (uint32_t)n_pad, h->d_bp_i8q);
+	if (h->int_mode == kU8L2 || n_pad != h->n) {
+		// own copy: whole 64-row tiles (zero rows behind the end), uint8 rows mapped to int8
+		void* copy = nullptr;
+		HIP_TRY(h, hipMalloc(&copy, n_pad * h->dim));
+		const size_t words = h->n * (size_t)h->dim / 4, words_pad = n_pad * (size_t)h->dim / 4;
+		hipLaunchKernelGGL(i8q_copy_xor_kernel, dim3(4096), dim3(kBlock), 0, st, (const uint32_t*)h->d_base,
+		                   words, words_pad, h->int_mode == kU8L2 ? 0x80808080u : 0u, (uint32_t*)copy);
+		h->d_base_i8q = copy;
+		h->base_i8q_owned = true;
+	} else {
+		h->d_base_i8q = h->d_base;
+		h->base_i8q_owned = false;
+	}
+	HIP_TRY(h, hipGetLastError());
+	return EXPANN_OK;
+}
+
+// sample pass -> thresholds -> full scan -> select, all in the g domain (scan_gemm_i8q.hpp)
+int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries, size_t m, size_t k,
+               uint64_t* d_ids, float* d_dists, hipStream_t st, uint32_t cap) {
+	const int cus = num_cus(h->device);
+	const bool dbg = std::getenv("EXPANN_DEBUG_SYNC") != nullptr;
+	auto mark = [&](const char* what) {
+		if (dbg) {
+			const hipError_t e = hipStreamSynchronize(st);
+			std::fprintf(stderr, "[i8q] %s: %s\n", what, hipGetErrorString(e));
+			std::fflush(stderr);
+		}
+	};
+	int rc = ensure_i8q(h, gq, st);
+	mark("ensure_i8q");
+	if (rc != EXPANN_OK)
+		return rc;
+	const void* q8 = d_queries;
+	if (h->int_mode == kU8L2) {  // queries ^ 0x80 (d_queries is the uint8 conversion, d_q8)
+		const size_t nb = m * (size_t)h->dim;
+		if (nb > h->q_split_bytes) {
+			if (h->d_q_split) hipFree(h->d_q_split);
+			h->d_q_split = nullptr;
+			h->q_split_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_q_split, nb));
+			h->q_split_bytes = nb;
+		}
+		hipLaunchKernelGGL(i8q_copy_xor_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
+		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, nb / 4, nb / 4, 0x80808080u,
+		                   (uint32_t*)h->d_q_split);
+		q8 = h->d_q_split;
+	}
+	const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
+	const uint32_t run = 16;
+	const uint32_t t_sel = std::max<uint32_t>(256, nt / (uint32_t)h->opt_sample_frac) / run * run;
+	const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
+	uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
+	chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
+	chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
+	if (t_sel * 2 > nt || (size_t)chunks * 32 < 8 * k)
+		return kRetryGeneric;
+	const int lds = h->dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>();
+	for (int attempt = 0;; ++attempt) {
+		rc = ensure_workspace(h, m, cap);
+		if (rc != EXPANN_OK)
+			return rc;
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
+		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
+		if (h->int_mode != kI8IP)
+			hipLaunchKernelGGL(gq->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+			                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)nullptr,
+			                   (int*)nullptr, h->d_qself);
+		const size_t need = m * (size_t)chunks * 32 * sizeof(int);
+		if (need > h->sample_bytes) {
+			if (h->d_sample) hipFree(h->d_sample);
+			h->d_sample = nullptr;
+			h->sample_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_sample, need));
+			h->sample_bytes = need;
+		}
+		GemmI8qParams sp{};
+		sp.base = h->d_base_i8q;
+		sp.bp = h->d_bp_i8q;
+		sp.bias = h->int_mode != kI8IP ? h->d_bias_i : nullptr;
+		sp.n_rows = (uint32_t)h->n;
+		sp.n_tiles_sel = t_sel;
+		sp.tile_stride = nt / t_sel;
+		sp.tile_run = run;
+		sp.tiles_per_block = (t_sel + chunks - 1) / chunks;
+		const uint32_t schunks = (t_sel + sp.tiles_per_block - 1) / sp.tiles_per_block;
+		sp.n_qtiles = nqt;
+		sp.queries = q8;
+		sp.m = (uint32_t)m;
+		sp.sample_out = (int*)h->d_sample;
+		sp.n_chunks = schunks;
+		if (dbg)
+			std::fprintf(stderr, "[i8q] sample: grid %u x %u, t_sel %u stride %u tpb %u chunks %u nt %u m %zu base %p bp %p q %p out %p (%zu B)\n",
+			             schunks, nqt, t_sel, sp.tile_stride, sp.tiles_per_block, schunks, nt, m, sp.base,
+			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->sample_bytes);
+		mark("qself");
+		hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), dim3(kF16Threads), lds, st, sp);
+		mark("sample");
+		SampleTauI8Params tp{};
+		tp.vals = (const int*)h->d_sample;
+		tp.n_vals = schunks * 32;
+		tp.m = (uint32_t)m;
+		tp.k = (uint32_t)k;
+		tp.thp = (int*)h->d_theta;
+		tp.cand_cnt = h->d_cnt;
+		hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_i8_kernel<8> : sample_tau_i8_kernel<32>,
+		                   dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, tp);
+		mark("tau");
+		// the full scan
+		GemmI8qParams fp = sp;
+		fp.sample_out = nullptr;
+		fp.n_tiles_sel = nt;
+		fp.tile_stride = 1;
+		fp.tile_run = 1;
+		fp.thp = (const int*)h->d_theta;
+		fp.qself = h->d_qself;
+		fp.cand_cnt = h->d_cnt;
+		fp.cand = h->d_cand;
+		fp.cap = cap;
+		uint32_t fchunks = 1;
+		{
+			const uint32_t slots = kF16WgPerCu * (uint32_t)cus;
+			const uint32_t gmax = std::max<uint32_t>(1, nt / 8);
+			double best = 1e300;
+			for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
+				const uint32_t steps = (nt + g - 1) / g;
+				const uint64_t rounds = ((uint64_t)g * nqt + slots - 1) / slots;
+				const double cost = (double)rounds * (steps + 4.0);
+				if (cost < best * 0.999) {
+					best = cost;
+					fchunks = g;
+				}
+			}
+		}
+		fp.tiles_per_block = (nt + fchunks - 1) / fchunks;
+		fchunks = (nt + fp.tiles_per_block - 1) / fp.tiles_per_block;
+		const bool timed = h->profiling && h->ev_used < kEventPairs;
+		if (timed)
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+		hipLaunchKernelGGL(gq->scan, dim3(fchunks * nqt), dim3(kF16Threads), lds, st, fp);
+		if (timed) {
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
+			h->ev_used++;
+		}
+		if (timed || !h->profiling) {
+			h->prof.scan_launches++;
+			h->prof.scan_rows += h->n;
+			h->prof.scan_query_tiles += nqt;
+			h->prof.query_tile = kF16TQ;
+			h->prof.levels = 2;
+			std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", gq->name);
+		}
+		HIP_TRY(h, hipGetLastError());
+		mark("scan");
+		SelectParams sel{};
+		sel.cand = h->d_cand;
+		sel.cand_cnt = h->d_cnt;
+		sel.cap = cap;
+		sel.k = (uint32_t)k;
+		sel.id_offset = h->id_offset;
+		sel.out_ids = d_ids;
+		sel.out_dists = d_dists;
+		sel.dim = (uint32_t)h->dim;
+		sel.overflow = h->d_overflow;
+		if (h->profiling)
+			hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
+			                   h->d_total);
+		hipLaunchKernelGGL(select_wave_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
+		                   dim3(kBlock), 0, st, sel, (uint32_t)m);
+		mark("select_wave");
+		sel.wave_done = 1;
+		hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock), sizeof(uint64_t) * cap + 16,
+		                   st, sel);
+		HIP_TRY(h, hipGetLastError());
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags + 4, h->d_total, sizeof(unsigned long long),
+		                          hipMemcpyDeviceToHost, st));
+		HIP_TRY(h, hipStreamSynchronize(st));
+		unsigned long long tot;
+		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
+		h->prof.candidates = tot;
+		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
+			return h->fail(EXPANN_ERR_UNSUPPORTED,
+			               std::to_string(h->h_flags[1]) +
+			                   " query values outside [0,255]: the uint8 metric "
+			                   "(dist2_compressed) is only defined for 8-bit valued queries");
+		if (h->h_flags[0] == 0)
+			return EXPANN_OK;
+		h->prof.retries++;
+		if (cap >= kMaxCap || attempt >= 2)
+			return kRetryGeneric;  // massive ties: the ladder's direct kernel breaks them by row
+		cap = std::min(cap * 4, kMaxCap);
+	}
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
@@ -542,6 +785,11 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "k too large for the candidate buffers (k <= " +
 		                                           std::to_string(kMaxCap / 2) + ")");
 	const int cus = num_cus(h->device);
+	if (const GemmI8qVariant* gq = pick_gemm_i8q(h, m, k)) {
+		const int rq = search_i8q(h, gq, d_queries, m, k, d_ids, d_dists, st, cap);
+		if (rq != kRetryGeneric)
+			return rq;
+	}
 	bool force_direct = false;  // set when a GEMM-form filter overflowed: massive near-ties
 	bool no_f16 = false;        // set when the queries do not fit the fp16 range of this index
 restart_direct:
@@ -1132,6 +1380,19 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 				delete h;
 				return EXPANN_ERR_HIP;
 			}
+	for (const auto& v : kGemmI8q)
+		if (v.d == dim)
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>()) !=
+			        hipSuccess ||
+			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>()) !=
+			        hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_i8q_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
 	for (const auto& v : kGemmBf16)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1183,6 +1444,8 @@ void expann_destroy(expann_index* h) {
 	if (h->d_bnorm_f16) hipFree(h->d_bnorm_f16);
 	if (h->d_qnrm) hipFree(h->d_qnrm);
 	if (h->d_sample) hipFree(h->d_sample);
+	if (h->d_base_i8q && h->base_i8q_owned) hipFree(h->d_base_i8q);
+	if (h->d_bp_i8q) hipFree(h->d_bp_i8q);
 	if (h->d_base_split) hipFree(h->d_base_split);
 	if (h->d_q_split) hipFree(h->d_q_split);
 	if (h->d_bias_i) hipFree(h->d_bias_i);
@@ -1267,6 +1530,14 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 	if (h->d_base_f16) {
 		hipFree(h->d_base_f16);
 		h->d_base_f16 = nullptr;
+	}
+	if (h->d_base_i8q && h->base_i8q_owned)
+		hipFree(h->d_base_i8q);
+	h->d_base_i8q = nullptr;
+	h->base_i8q_owned = false;
+	if (h->d_bp_i8q) {
+		hipFree(h->d_bp_i8q);
+		h->d_bp_i8q = nullptr;
 	}
 	if (h->d_bnorm_f16) {
 		hipFree(h->d_bnorm_f16);

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(kBlock) void query_theta_i8_kernel(const void* quer
 		}
 		acc = reduce16_i32(acc);
 	}
-	if (qi < m && l == 0) {
+	if (qi < m && l == 0 && !tau)
+		qself[qi] = acc;  // (only the query term is wanted: scan_gemm_i8q.hpp)
+	if (qi < m && l == 0 && tau) {
 		const float t = tau[qi];
 		// floor(tau) clamped into int32 (scores are integers of magnitude < 2^31)
 		int ft;

@@ -1,0 +1,418 @@
+// scan_gemm_i8q.hpp -- the 8-bit GEMM-form filter in the geometry of scan_gemm_f16.hpp
+// (256-thread workgroups, two per CU; 64 queries x 64 rows = 2x2 MFMA tiles per wave and step;
+// LDS-DMA staging with counted vmcnt waits; per-wave hit queues in LDS; one sampled pass for the
+// threshold), on the int8 matrix cores (v_mfma_i32_32x32x32_i8), for d = 128 and 256.
+// (d = 768 keeps scan_gemm_i8.hpp: its query fragments alone are 96 VGPRs per 32 queries.)
+//
+// Integer arithmetic is exact, so the filter needs no slack and no re-rank.  Everything runs in
+// the "g domain":  g(q, b) = q.b - bp[b],  bp[b] = floor(bias[b] / 2),  bias[b] = sum b^2 (L2
+// forms; 0 for the inner product).  With score = qself + bias - 2 q.b (L2) or -q.b (IP):
+//     score(q, b)  =  qself - 2 g - (bias & 1)    (L2)          score = -g   (IP)
+// so larger g = nearer row, up to the parity bit.  The sampled pass returns class maxima of g;
+// the k-th largest of them, g_k, belongs to k different rows, and the full scan keeps every
+// row with g >= g_k: the accumulators start at -g_k and a row passes when acc >= bp.  A kept row
+// may score one unit above the k-th (parity), never the reverse, so no neighbour is lost;
+// candidates leave the kernel with their exact integer scores.
+// uint8 rows (src/antitopo_engine.h:38-61) are mapped to int8 by x ^ 0x80 on both sides when
+// the engine makes its padded copy of the index (differences, hence scores, unchanged).
+#pragma once
+#include "common.hpp"
+#include "scan_gemm_f16.hpp"
+#include "scan_gemm_i8.hpp"
+
+namespace expann {
+
+constexpr int kI8qPadBp = 1 << 30;  // bp of the padding rows: no accumulator reaches it (flush checks the row too)
+
+struct GemmI8qParams {
+	const void* base;        // [n_rows padded to 64][D] int8 (uint8 rows already ^ 0x80)
+	const int* bp;           // [padded] floor(bias/2); kI8qPadBp on the padding
+	const int* bias;         // [n_rows] sum b^2 (L2 forms) or nullptr (IP)
+	uint32_t n_rows;
+	uint32_t n_tiles_sel;
+	uint32_t tile_stride;
+	uint32_t tile_run;
+	uint32_t tiles_per_block;
+	uint32_t n_qtiles;
+	const void* queries;     // [m][D] int8 (uint8 queries already ^ 0x80)
+	const int* thp;          // [m] accumulator start = -g_k
+	const int* qself;        // [m] sum q^2 (L2 forms) or nullptr
+	uint32_t m;
+	uint32_t* cand_cnt;
+	uint64_t* cand;
+	uint32_t cap;
+	int* sample_out;         // SAMPLE: [(q * n_chunks + chunk) * 32 + class] max g
+	uint32_t n_chunks;
+};
+
+// bp[i] = bias[i] >> 1 for i < n, kI8qPadBp for n <= i < n_pad (bias == nullptr: zeros)
+__global__ __launch_bounds__(kBlock) void i8q_bp_kernel(const int* bias, uint32_t n, uint32_t n_pad,
+                                                        int* bp) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < n_pad)
+		bp[i] = i < n ? (bias ? bias[i] >> 1 : 0) : kI8qPadBp;
+}
+// out[i] = in[i] ^ x (bytes, 4 at a time) for i < n_words; zero for n_words <= i < n_words_pad
+__global__ __launch_bounds__(kBlock) void i8q_copy_xor_kernel(const uint32_t* in, size_t n_words,
+                                                              size_t n_words_pad, uint32_t x,
+                                                              uint32_t* out) {
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_words_pad;
+	     i += (size_t)gridDim.x * kBlock)
+		out[i] = i < n_words ? in[i] ^ x : 0u;
+}
+
+__device__ inline int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int D> constexpr int gemm_i8q_lds_bytes() {
+	return kF16Bufs * (kF16TB * D + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes +
+	       kF16TQ * 4 + 16;
+}
+
+template <int D, bool L2FORM, bool SAMPLE>
+__global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qParams p) {
+	static_assert(D == 128 || D == 256, "built for d = 128, 256");
+	constexpr int ROWB = D;          // bytes per row
+	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
+	constexpr int KS = D / 32;       // MFMA k-steps; lane half h of k-step s holds chunk h*KS + s
+	constexpr int TILE_BYTES = kF16TB * ROWB;
+	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
+	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
+	constexpr int PF = kF16Prefetch, NBUF = kF16Bufs;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int h = lane >> 5, r31 = lane & 31;
+	const uint32_t qtile = blockIdx.x % p.n_qtiles;
+	const uint32_t chunk = blockIdx.x / p.n_qtiles;
+	const uint32_t wg_q0 = qtile * kF16TQ;
+	const uint32_t q0 = wg_q0 + wave * 64;
+
+	const uint32_t t0 = chunk * p.tiles_per_block;
+	uint32_t t1 = t0 + p.tiles_per_block;
+	if (t1 > p.n_tiles_sel)
+		t1 = p.n_tiles_sel;
+	if (t0 >= t1)
+		return;  // (whole workgroup)
+
+	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
+	struct QEntry {
+		int acc[16];
+		int bp;
+		uint32_t row;
+		uint32_t qrow0;
+		uint32_t pad;
+	};
+	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
+	QEntry* const queue =
+	    reinterpret_cast<QEntry*>(bn_slots + NBUF * kF16Waves * 256) + wave * kF16WaveQueue;
+	int* const thq = reinterpret_cast<int*>(bn_slots + NBUF * kF16Waves * 256 +
+	                                        kF16Waves * kF16WaveQueue * kF16EntryBytes);
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + kF16TQ);
+
+	constexpr int kNever = -2147483647 - 1;
+	i32x4 a[2][KS];
+#pragma unroll
+	for (int tq = 0; tq < 2; ++tq) {
+		uint32_t qi = q0 + tq * 32 + r31;
+		if (qi >= p.m)
+			qi = p.m - 1;
+		const i32x4* src =
+		    reinterpret_cast<const i32x4*>((const unsigned char*)p.queries + (size_t)qi * ROWB);
+#pragma unroll
+		for (int s = 0; s < KS; ++s)
+			a[tq][s] = src[h * KS + s];
+	}
+	// accumulator start values -g_k (SAMPLE: zero starts; th holds the running class maxima)
+	i32x16 th[2];
+#pragma unroll
+	for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+		for (int reg = 0; reg < 16; ++reg) {
+			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+			// a padded query slot starts at INT_MIN/2: dot + that never reaches a bp >= 0
+			th[tq][reg] = SAMPLE ? kNever : (qi < p.m ? p.thp[qi] : kNever / 2);
+		}
+	if (!SAMPLE)
+		thq[tid] = wg_q0 + tid < p.m ? p.thp[wg_q0 + tid] : kNever / 2;
+#pragma unroll
+	for (int tq = 0; tq < 2; ++tq) {
+#pragma unroll
+		for (int s = 0; s < KS; ++s)
+			asm volatile("" : "+v"(a[tq][s]));
+		asm volatile("" : "+v"(th[tq]));
+	}
+	static_assert((32 / RPB) % (SWM + 1) == 0, "swizzle must repeat every 32 rows");
+	uint32_t aoff[KS];
+#pragma unroll
+	for (int s = 0; s < KS; ++s)
+		aoff[s] = r31 * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
+
+	auto tile_row0 = [&](uint32_t t) -> uint32_t {
+		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kF16TB;
+	};
+	constexpr int ROWS_PER_INSTR = kF16Threads / CH;
+	static_assert(ROWS_PER_INSTR % (16 * RPB) == 0, "swizzle must be instruction-invariant");
+	constexpr int N_STAGE = kF16TB * CH / kF16Threads;
+	constexpr int LOADS = N_STAGE + 1;
+	const uint32_t lane_row = tid / CH;
+	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
+	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
+		if (i < N_STAGE) {
+			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
+			__builtin_amdgcn_global_load_lds(
+			    (const __attribute__((address_space(1))) void*)(tb + (uint32_t)i * ROWS_PER_INSTR * ROWB),
+			    (__attribute__((address_space(3))) void*)(dst0 + i * kF16Threads * 16), 16, 0, 0);
+		} else {
+			__builtin_amdgcn_global_load_lds(
+			    (const __attribute__((address_space(1))) void*)(p.bp + row0 + lane),
+			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0,
+			    0);
+		}
+	};
+	auto stage_src = [&](uint32_t t, uint32_t& row0) -> const unsigned char* {
+		if (t > t1 - 1)
+			t = t1 - 1;
+		row0 = tile_row0(t);
+		return (const unsigned char*)p.base + (size_t)row0 * ROWB + lane_off;
+	};
+	auto stage = [&](uint32_t t, int buf) {
+		uint32_t row0;
+		const unsigned char* tb = stage_src(t, row0);
+#pragma unroll
+		for (int i = 0; i < LOADS; ++i)
+			stage_piece(tb, row0, buf, i);
+	};
+	auto read_bp = [&](int (&bv)[2], int buf) {
+		const int* slot = reinterpret_cast<const int*>(bn_slots + (buf * kF16Waves + wave) * 256);
+		bv[0] = slot[r31];
+		bv[1] = slot[32 + r31];
+	};
+
+	uint32_t wfill = 0;  // wave-uniform
+	auto push_global = [&](uint32_t qi, int acc, uint32_t row) {
+		// exact integer score from the accumulator: dot = acc - thp[q]
+		const int dot = acc - thq[(qi - wg_q0) & (kF16TQ - 1)];
+		const int score = L2FORM ? p.bias[row] - 2 * dot + p.qself[qi] : -dot;
+		const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
+		if (slot < p.cap)
+			p.cand[(size_t)qi * p.cap + slot] = make_key((float)score, row);
+	};
+	auto flush_own = [&]() {
+		const uint32_t n = wfill < (uint32_t)kF16WaveQueue ? wfill : (uint32_t)kF16WaveQueue;
+		constexpr int R = 4;
+		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
+			bool hit[R];
+			uint32_t qi[R], slot[R], row[R];
+			int dot[R];
+#pragma unroll
+			for (int j = 0; j < R; ++j) {
+				const uint32_t i = base + j * 64 + lane;
+				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
+				const uint32_t reg = i & 15;
+				const int c = e.acc[reg];
+				row[j] = e.row;
+				hit[j] = i < n * 16 && c >= e.bp && row[j] < p.n_rows;
+				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
+				dot[j] = c - thq[(qi[j] - wg_q0) & (kF16TQ - 1)];
+			}
+			int score[R];
+#pragma unroll
+			for (int j = 0; j < R; ++j)
+				score[j] = !hit[j] ? 0 : (L2FORM ? p.bias[row[j]] - 2 * dot[j] + p.qself[qi[j]] : -dot[j]);
+#pragma unroll
+			for (int j = 0; j < R; ++j)
+				slot[j] = hit[j] ? atomicAdd(&p.cand_cnt[qi[j]], 1u) : 0xFFFFFFFFu;
+#pragma unroll
+			for (int j = 0; j < R; ++j)
+				if (hit[j] && slot[j] < p.cap)
+					p.cand[(size_t)qi[j] * p.cap + slot[j]] = make_key((float)score[j], row[j]);
+		}
+		wfill = 0;
+	};
+	auto epilogue = [&](const i32x16 (&accs)[2][2], uint32_t row0, const int (&bv)[2]) {
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+			for (int tc = 0; tc < 2; ++tc) {
+				const i32x16& c = accs[tq][tc];
+				const int bn = bv[tc];
+				int m0 = max3i(c[0], c[1], c[2]);
+				int m1 = max3i(c[3], c[4], c[5]);
+				int m2 = max3i(c[6], c[7], c[8]);
+				int m3 = max3i(c[9], c[10], c[11]);
+				int m4 = max3i(c[12], c[13], c[14]);
+				m0 = max3i(m0, m1, c[15]);
+				m2 = max3i(m2, m3, m4);
+				m0 = max(m0, m2);
+				const unsigned long long mask = __builtin_amdgcn_ballot_w64(m0 >= bn);
+				if (mask != 0) {
+					uint32_t qrow0 = q0 + tq * 32 + 4 * h;  // rare path: arithmetic stays in here
+					asm volatile("" : "+v"(qrow0));
+					const uint32_t brow = row0 + tc * 32 + r31;
+					const uint32_t slot =
+					    wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+					                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+					if (m0 >= bn) {
+						if (slot < (uint32_t)kF16WaveQueue) {
+							QEntry& e = queue[slot];
+#pragma unroll
+							for (int reg = 0; reg < 16; ++reg)
+								e.acc[reg] = c[reg];
+							e.bp = bn;
+							e.row = brow;
+							e.qrow0 = qrow0;
+						} else if (brow < p.n_rows) {  // queue full: straight to the lists
+#pragma unroll 1
+							for (int reg = 0; reg < 16; ++reg) {
+								int cr = c[0];
+#pragma unroll
+								for (int j = 1; j < 16; ++j)
+									cr = reg == j ? c[j] : cr;
+								if (cr >= bn)
+									push_global(qrow0 + (reg & 3) + 8 * (reg >> 2), cr, brow);
+							}
+						}
+					}
+					wfill += (uint32_t)__builtin_popcountll(mask);
+				}
+			}
+	};
+
+#pragma unroll
+	for (int i = 0; i < PF; ++i)
+		stage(t0 + i, i);
+	wait_vm_then_barrier<(PF - 1) * LOADS>();
+
+	i32x16 acc[2][2];
+	i32x16 zero16;
+#pragma unroll
+	for (int e = 0; e < 16; ++e)
+		zero16[e] = 0;
+	int bv[2];
+	int buf = 0, pbuf = PF;
+	uint32_t since_look = 0;
+	for (uint32_t t = t0; t < t1; ++t) {
+		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
+		auto frag = [&](int tc, int s) -> i32x4 {
+			return *reinterpret_cast<const i32x4*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
+		};
+		uint32_t srow0;
+		const unsigned char* stb = stage_src(t + PF, srow0);
+		i32x4 fb[KS][2];
+		fb[0][0] = frag(0, 0);
+		fb[0][1] = frag(1, 0);
+		fb[1][0] = frag(0, 1);
+		fb[1][1] = frag(1, 1);
+		read_bp(bv, buf);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int s = 0; s < KS; ++s) {
+			if (s + 2 < KS) {
+				fb[s + 2][0] = frag(0, s + 2);
+				fb[s + 2][1] = frag(1, s + 2);
+			}
+#pragma unroll
+			for (int tq = 0; tq < 2; ++tq) {
+				acc[tq][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
+				acc[tq][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+				    a[tq][s], fb[s][1], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
+			}
+			// the stage loads of tile t+PF go out between the MFMAs (LOADS may exceed KS at d = 256)
+			constexpr int PER = (LOADS + KS - 1) / KS;
+#pragma unroll
+			for (int j = 0; j < PER; ++j)
+				if (s * PER + j < LOADS)
+					stage_piece(stb, srow0, pbuf, s * PER + j);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (SAMPLE) {
+#pragma unroll
+			for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+				for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+					for (int reg = 0; reg < 16; ++reg)
+						th[tq][reg] = max(th[tq][reg], acc[tq][tc][reg] - bv[tc]);
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
+		} else {
+			epilogue(acc, tile_row0(t), bv);
+			const bool look = ++since_look == kF16FlushEvery;
+			if (look && lane == 0)
+				fills[wave] = wfill;
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
+			if (look) {
+				since_look = 0;
+				const uint32_t f = fills[lane & (kF16Waves - 1)];
+				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)kF16WaveQueue / 2) != 0)
+					flush_own();
+			}
+		}
+		pbuf = buf;
+		buf = buf + 1 == NBUF ? 0 : buf + 1;
+	}
+	if (SAMPLE) {
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+			for (int reg = 0; reg < 16; ++reg) {
+				const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+				if (qi < p.m)
+					p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[tq][reg];
+			}
+	} else {
+		flush_own();
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tiles: LDS must outlive them
+}
+
+// thp[q] = -g_k, g_k the k-th largest of the n_vals class maxima of the SAMPLE pass (fewer than k
+// real values: pass everything); also zeroes the query's list counter.  One wave per query.
+struct SampleTauI8Params {
+	const int* vals;    // [m][n_vals]
+	uint32_t n_vals;
+	uint32_t m;
+	uint32_t k;
+	int* thp;           // [m]
+	uint32_t* cand_cnt; // [m] <- 0
+};
+template <int PER>
+__global__ __launch_bounds__(kBlock) void sample_tau_i8_kernel(SampleTauI8Params p) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (qi >= p.m)
+		return;  // (whole wave)
+	const int* v = p.vals + (size_t)qi * p.n_vals;
+	// keys ordered like g: (g ^ sign) << 32 | unique index; 0 = empty / taken
+	uint64_t keys[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const uint32_t i = j * 64 + lane;
+		keys[j] = i < p.n_vals ? ((uint64_t)((uint32_t)v[i] ^ 0x80000000u) << 32) | (0xFFFFFFFFu - i) : 0ull;
+	}
+	uint64_t kth = 0;
+	for (uint32_t it = 0; it < p.k; ++it) {
+		uint64_t best = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			best = keys[j] > best ? keys[j] : best;
+		for (int off = 32; off > 0; off >>= 1) {
+			const uint64_t o = __shfl_xor(best, off);
+			best = o > best ? o : best;
+		}
+		kth = best;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			keys[j] = keys[j] == best ? 0ull : keys[j];
+	}
+	if (lane == 0) {
+		const int g = (int)((uint32_t)(kth >> 32) ^ 0x80000000u);
+		// no k-th value, or a maximum that only padding produced: keep every row
+		p.thp[qi] = (kth == 0 || g < -(1 << 29)) ? (1 << 30) : -g;
+		p.cand_cnt[qi] = 0;
+	}
+}
+
+}  // namespace expann

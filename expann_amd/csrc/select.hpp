@@ -197,7 +197,7 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
 }
 
 // The same job as select_small, one WAVE per query (lists of <= kSelectWaveMax candidates of a
-// GEMM-form scan): the chain count -> keys -> candidate rows -> output is three dependent
+// GEMM-form scan; rerank_base == nullptr: the keys already carry their final scores): the chain count -> keys -> candidate rows -> output is three dependent
 // memory round trips whatever the arithmetic, so the win is 4x the queries in flight and no
 // workgroup barriers.  Longer lists are left to select_topk_kernel (which skips the queries
 // done here when p.wave_done is set).
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uin
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS ops are in order)
 	// exact re-score, two candidates per 16-lane group in flight; slot i is read and rewritten
-	// by the one group that owns it
-	for (uint32_t i0 = 0; i0 < n_s; i0 += 8) {
+	// by the one group that owns it.  (Lists with final scores -- the 8-bit forms -- skip it.)
+	for (uint32_t i0 = 0; p.rerank_base && i0 < n_s; i0 += 8) {
 		float acc[2];
 		uint32_t row[2];
 #pragma unroll

@@ -182,7 +182,7 @@ int expann_get_profile(expann_index* h, expann_profile* out);
 /* integer options: "query_tile" (0 = auto), "cand_capacity" (0 = auto),
  * "scan_kernel" (0 = auto, 1 = direct VALU scan, 2 = GEMM form on the fp32 / int8 matrix
  * cores, 3 = GEMM form on the bf16 matrix cores with the 3-term split, 4 = GEMM form with one
- * scaled fp16 product; the final ids and distances are identical for every choice),
+ * scaled fp16 product, 5 = 8-bit rows: int8 MFMA form with per-wave hit queues (d = 128, 256); the final ids and distances are identical for every choice),
  * "sample_ratio" (rows ratio between threshold levels, default 32). */
 int expann_set_option(expann_index* h, const char* name, long value);
 

@@ -4,10 +4,13 @@ run() { timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | p
 import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
 print(' '.join(sys.argv[1:]), '| QPS', j['value'], 'ms/step', j['ms_per_step'], 'scan_ms', r['kernel_ms'], r['kernel'], 'frac', r['frac'], 'cands', r['candidates_per_query'])" "$@"; }
+if [ $# -gt 0 ]; then run "$@"; exit 0; fi
 run --n 1250000 --k 100 --steps 5
 run --n 10000000 --k 100 --steps 3
 run --n 1000000 --k 10 --m 1000 --steps 20
 run --n 1000000 --k 10 --m 256 --steps 20
 run --n 1000000 --d 64 --k 10 --steps 10
 run --n 1000000 --dtype u8 --steps 10
+run --n 1000000 --dtype i8 --metric ip --steps 10
+run --n 1000000 --d 256 --dtype i8 --steps 10
 run --workload c5 --steps 3

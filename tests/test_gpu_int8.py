@@ -135,6 +135,32 @@ def test_gemm_form_int8_mfma(oracle, dtype, metric, ometric, d, n, m, k):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,metric,ometric,d", [
+    ("u8", "l2", "METRIC_L2_U8", 128), ("u8", "l2", "METRIC_L2_U8", 256),
+    ("i8", "l2", "METRIC_L2_I8", 128), ("i8", "ip", "METRIC_IP_I8", 128),
+    ("i8", "l2", "METRIC_L2_I8", 256), ("i8", "ip", "METRIC_IP_I8", 256),
+])
+@pytest.mark.parametrize("n,m,k", [(40000, 130, 10), (70001, 300, 17), (65536, 97, 100)])
+def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
+    """scan_kernel=5: the int8-MFMA form in the fp16 kernel's geometry (sampled class-maxima pass
+    for the threshold, per-wave hit queues; scan_gemm_i8q.hpp) -- exact integer scores, ties by
+    row number, ragged last tile (the engine pads its own copy)."""
+    rng = np.random.RandomState(n + d + m)
+    if dtype == "u8":
+        base = _sift_like(rng, n, d).astype(np.uint8)
+        queries = np.minimum(_sift_like(rng, m, d) + rng.uniform(0, 0.99, size=(m, d)),
+                             255.5).astype(np.float32)
+    else:
+        base = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
+        queries = rng.randint(-128, 128, size=(m, d)).astype(np.int8)
+    eng = _engine(base, metric, dtype)
+    eng.set_option("scan_kernel", 5)
+    eng.set_profiling(True)
+    _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
+    assert eng.get_profile()["scan_kernel"].startswith("scan_gemm_i8q"), eng.get_profile()["scan_kernel"]
+    eng.close()
+
+
 def test_quantizer_builds_on_device(oracle):
     """quantizer_simple<uint8_t> (cast) and quantizer_ranged_q8 (affine int8) vs the oracle."""
     import ctypes as C
