@@ -108,7 +108,7 @@ struct expann_index {
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
 	long opt_debug = 0;
-	long opt_sample_frac = 16;       // the sampled pass reads 1/opt_sample_frac of the rows
+	long opt_sample_frac = 0;        // the sampled pass reads 1/frac of the rows; 0 = by k (sample_frac_for)
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
@@ -495,6 +495,29 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 	return EXPANN_OK;
 }
 
+// Rows read by the sampled pass = 1/frac.  Its cost falls with frac, the candidates of the full
+// scan (~1.2 k frac per query) grow with it: the optimum moves as 1/sqrt(k); 16 at k = 10 (measured
+// flat from 12 to 16), 5 at k = 100.
+// one wave per query for lists of <= 512 keys, then (when the buffers allow longer lists) for
+// <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
+void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st) {
+	const dim3 grid((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64)));
+	sel.wave_done = 0;
+	hipLaunchKernelGGL(select_wave_kernel<8>, grid, dim3(kBlock), 0, st, sel, (uint32_t)m);
+	sel.wave_done = 512;
+	if (cap > 512) {
+		hipLaunchKernelGGL(select_wave_kernel<32>, grid, dim3(kBlock), 0, st, sel, (uint32_t)m);
+		sel.wave_done = 2048;
+	}
+}
+
+uint32_t sample_frac_for(const expann_index* h, size_t k) {
+	if (h->opt_sample_frac > 0)
+		return (uint32_t)h->opt_sample_frac;
+	const double f = 16.0 * std::sqrt(10.0 / (double)std::max<size_t>(1, k));
+	return (uint32_t)std::min(32.0, std::max(4.0, std::round(f)));
+}
+
 // ---- 8-bit GEMM form, queue geometry (scan_gemm_i8q.hpp), d = 128 / 256 ----------------------
 using GemmI8qFn = void (*)(GemmI8qParams);
 struct GemmI8qVariant {
@@ -589,7 +612,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	}
 	const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
 	const uint32_t run = 16;
-	const uint32_t t_sel = std::max<uint32_t>(256, nt / (uint32_t)h->opt_sample_frac) / run * run;
+	const uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 	const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
 	uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
 	chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
@@ -644,7 +667,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		tp.k = (uint32_t)k;
 		tp.thp = (int*)h->d_theta;
 		tp.cand_cnt = h->d_cnt;
-		hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_i8_kernel<8> : sample_tau_i8_kernel<32>,
+		hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_i8_kernel<8>
+		                                   : (tp.n_vals <= 1024 ? sample_tau_i8_kernel<16> : sample_tau_i8_kernel<32>),
 		                   dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, tp);
 		mark("tau");
 		// the full scan
@@ -706,10 +730,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		if (h->profiling)
 			hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
 			                   h->d_total);
-		hipLaunchKernelGGL(select_wave_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
-		                   dim3(kBlock), 0, st, sel, (uint32_t)m);
+		launch_select_wave(sel, m, cap, st);
 		mark("select_wave");
-		sel.wave_done = 1;
 		hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock), sizeof(uint64_t) * cap + 16,
 		                   st, sel);
 		HIP_TRY(h, hipGetLastError());
@@ -886,7 +908,7 @@ restart_direct:
 		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
 			const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
 			const uint32_t run = 16;
-			uint32_t t_sel = std::max<uint32_t>(256, nt / (uint32_t)h->opt_sample_frac) / run * run;
+			uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 			const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
 			uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
 			chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
@@ -933,7 +955,8 @@ restart_direct:
 				tp.mul = 0.5f * h->f16_scale * h->f16_scale;
 				tp.cand_cnt = h->d_cnt;
 				theta_ready = true;
-				hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_kernel<8> : sample_tau_kernel<32>,
+				hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_kernel<8>
+		                                   : (tp.n_vals <= 1024 ? sample_tau_kernel<16> : sample_tau_kernel<32>),
 				                   dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
 				                   tp);
 				HIP_TRY(h, hipGetLastError());
@@ -1226,9 +1249,7 @@ restart_direct:
 				                   h->d_total);
 			if (sel.rerank_base && sel.cand_cnt && !(h->opt_debug & 512)) {
 				// short lists (the usual case after a GEMM-form scan): one wave per query
-				hipLaunchKernelGGL(select_wave_kernel, dim3((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64))),
-				                   dim3(kBlock), 0, st, sel, (uint32_t)m);
-				sel.wave_done = 1;
+				launch_select_wave(sel, m, cap, st);
 			}
 			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
 			                   sizeof(uint64_t) * cap + 16, st, sel);
@@ -2194,7 +2215,7 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "sample_frac"))
-		h->opt_sample_frac = value < 2 ? 2 : value;
+		h->opt_sample_frac = value < 0 ? 0 : value;
 	else if (!std::strcmp(name, "sample_ratio"))
 		h->opt_sample_ratio = value < 2 ? 2 : value;
 	else

@@ -31,6 +31,7 @@
 #pragma once
 #include "common.hpp"
 #include "scan_gemm_bf16.hpp"
+#include "select.hpp"
 
 namespace expann {
 
@@ -531,6 +532,13 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
 	uint64_t kth = 0;
+	if (p.k > 24) {  // bisection on the value: 32 steps whatever k
+		uint32_t ord[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			ord[j] = (uint32_t)(keys[j] >> 32);
+		kth = (uint64_t)wave_kth_largest_u32<PER>(ord, p.k) << 32;
+	} else
 	for (uint32_t it = 0; it < p.k; ++it) {
 		uint64_t best = 0;
 #pragma unroll

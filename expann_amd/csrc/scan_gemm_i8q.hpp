@@ -393,6 +393,13 @@ __global__ __launch_bounds__(kBlock) void sample_tau_i8_kernel(SampleTauI8Params
 		keys[j] = i < p.n_vals ? ((uint64_t)((uint32_t)v[i] ^ 0x80000000u) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
 	uint64_t kth = 0;
+	if (p.k > 24) {
+		uint32_t ord[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			ord[j] = (uint32_t)(keys[j] >> 32);
+		kth = (uint64_t)wave_kth_largest_u32<PER>(ord, p.k) << 32;
+	} else
 	for (uint32_t it = 0; it < p.k; ++it) {
 		uint64_t best = 0;
 #pragma unroll

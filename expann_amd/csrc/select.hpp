@@ -35,7 +35,7 @@ struct SelectParams {
 	float prune_abs;          // absolute slack coefficient (fp16 form): + prune_abs*(|q| + |b|max)
 	const float* bn_max;      // [1] max over rows of ||b||^2 (1-eps)
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
-	uint32_t wave_done;       // select_wave_kernel already served the lists of <= kSelectWaveMax keys
+	uint32_t wave_done;       // select_wave_kernel already served the lists of <= wave_done keys
 };
 
 // statistics: *out = sum of counts (one workgroup; one same-address atomic per query in the
@@ -201,9 +201,77 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
 // memory round trips whatever the arithmetic, so the win is 4x the queries in flight and no
 // workgroup barriers.  Longer lists are left to select_topk_kernel (which skips the queries
 // done here when p.wave_done is set).
-constexpr uint32_t kSelectWaveMax = 512;
+// the k smallest of the n_s <= 64*NE keys in list[], ascending, to the outputs (+ the next tau):
+// k rounds of wave-min extraction, lane 0 writes
+template <int NE>
+__device__ inline void wave_emit_sorted(const SelectParams& p, const uint64_t* list, uint32_t n_s,
+                                        uint32_t qi, int lane) {
+	uint64_t e[NE];
+#pragma unroll
+	for (int j = 0; j < NE; ++j)
+		e[j] = lane + 64 * j < (int)n_s ? list[lane + 64 * j] : kSentinelKey;
+	for (uint32_t r = 0; r < p.k; ++r) {
+		uint64_t mn = e[0];
+#pragma unroll
+		for (int j = 1; j < NE; ++j)
+			mn = e[j] < mn ? e[j] : mn;
+		mn = wave_min_u64(mn);
+		const bool ok = mn != kSentinelKey;
+		if (lane == 0) {
+			if (p.out_ids)
+				p.out_ids[(size_t)qi * p.k + r] = ok ? (uint64_t)key_idx(mn) + p.id_offset : ~0ull;
+			if (p.out_dists)
+				p.out_dists[(size_t)qi * p.k + r] = ok ? key_score(mn) : __builtin_inff();
+			if (r == p.k - 1 && p.tau_out) {
+				p.tau_out[qi] = ok ? key_score(mn) : (p.tau_prev ? p.tau_prev[qi] : __builtin_inff());
+				if (p.tau_row_out)
+					p.tau_row_out[qi] = ok ? key_idx(mn) : (p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < NE; ++j)
+			e[j] = e[j] == mn ? kSentinelKey : e[j];
+	}
+}
 
+// k-th smallest of the 64*PER values held by a wave (duplicates counted; all-ones = absent):
+// bisection on the value, one ballot + popcount per element and step -- 32 steps whatever k
+template <int PER> __device__ inline uint32_t wave_kth_smallest_u32(const uint32_t (&v)[PER], uint32_t k) {
+	uint32_t lo = 0, hi = 0xFFFFFFFFu;  // smallest x with count(v <= x) >= k
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[j] <= mid));
+		if (cnt >= k)
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	return lo;
+}
+
+// k-th largest (0 = absent; 0 is returned when fewer than k values are present)
+template <int PER> __device__ inline uint32_t wave_kth_largest_u32(const uint32_t (&v)[PER], uint32_t k) {
+	uint32_t lo = 0, hi = 0xFFFFFFFFu;  // largest x with count(v >= x) >= k
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1);
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[j] >= mid));
+		if (cnt >= k)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	return lo;
+}
+
+template <int PER>  // lists of (64 * PER / 4, 64 * PER] keys (PER = 8: of at most 512)
 __global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uint32_t m) {
+	constexpr uint32_t kSelectWaveMax = 64 * PER;
 	__shared__ uint64_t lists[kBlock / 64][kSelectWaveMax];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,11 +279,10 @@ __global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uin
 	if (qi >= m)
 		return;
 	const uint32_t c = p.cand_cnt[qi];
-	if (c > kSelectWaveMax)
-		return;
+	if (c > kSelectWaveMax || c > p.cap || (c <= p.wave_done && p.wave_done != 0))
+		return;  // longer lists: the next size up; shorter ones: already served
 	uint64_t* list = lists[wave];
 	const uint64_t* src = p.cand + (size_t)qi * p.cap;
-	constexpr int PER = kSelectWaveMax / 64;
 	uint64_t kk[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j)
@@ -234,6 +301,9 @@ __global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uin
 		for (int j = 0; j < PER; ++j)
 			sc[j] = (uint32_t)(kk[j] >> 32);
 		uint32_t kth = 0xFFFFFFFFu;
+		if (p.k > 24) {
+			kth = wave_kth_smallest_u32<PER>(sc, p.k);
+		} else
 		for (uint32_t r = 0; r < p.k; ++r) {
 			uint32_t mn = sc[0];
 #pragma unroll
@@ -295,32 +365,10 @@ __global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uin
 		}
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	uint64_t e[PER];
-#pragma unroll
-	for (int j = 0; j < PER; ++j)
-		e[j] = lane + 64 * j < (int)n_s ? list[lane + 64 * j] : kSentinelKey;
-	for (uint32_t r = 0; r < p.k; ++r) {
-		uint64_t mn = e[0];
-#pragma unroll
-		for (int j = 1; j < PER; ++j)
-			mn = e[j] < mn ? e[j] : mn;
-		mn = wave_min_u64(mn);
-		const bool ok = mn != kSentinelKey;
-		if (lane == 0) {
-			if (p.out_ids)
-				p.out_ids[(size_t)qi * p.k + r] = ok ? (uint64_t)key_idx(mn) + p.id_offset : ~0ull;
-			if (p.out_dists)
-				p.out_dists[(size_t)qi * p.k + r] = ok ? key_score(mn) : __builtin_inff();
-			if (r == p.k - 1 && p.tau_out) {
-				p.tau_out[qi] = ok ? key_score(mn) : (p.tau_prev ? p.tau_prev[qi] : __builtin_inff());
-				if (p.tau_row_out)
-					p.tau_row_out[qi] = ok ? key_idx(mn) : (p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu);
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < PER; ++j)
-			e[j] = e[j] == mn ? kSentinelKey : e[j];
-	}
+	if (n_s <= 256)
+		wave_emit_sorted<(PER < 4 ? PER : 4)>(p, list, n_s, qi, lane);
+	else
+		wave_emit_sorted<PER>(p, list, n_s, qi, lane);
 }
 
 // One workgroup per query: bitonic sort of the (power-of-two padded) key list in LDS.
@@ -330,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	const uint32_t qi = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	uint32_t c = p.cand_cnt ? p.cand_cnt[qi] : p.fixed_count;
-	if (p.wave_done && c <= kSelectWaveMax)
+	if (p.wave_done && c <= p.wave_done)
 		return;  // (uniform per workgroup)
 	if (c > p.cap) {
 		if (tid == 0)
