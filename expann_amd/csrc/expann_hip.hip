@@ -532,8 +532,14 @@ struct GemmI8qVariant {
 	"scan_gemm_i8q<" #D "," MN ">"}
 const GemmI8qVariant kGemmI8q[] = {
     GEMM_I8Q(128, kU8L2, true, "U8L2"), GEMM_I8Q(128, kI8L2, true, "I8L2"), GEMM_I8Q(128, kI8IP, false, "I8IP"),
-    GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP")};
+    GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP"),
+    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP")};
 #undef GEMM_I8Q
+int i8q_lds_bytes(int d) {
+	return d == 128 ? gemm_i8q_lds_bytes<128>() : (d == 256 ? gemm_i8q_lds_bytes<256>() : gemm_i8q_lds_bytes<768>());
+}
+int i8q_threads(int d) { return d == 768 ? I8qGeom<768>::THREADS : I8qGeom<128>::THREADS; }
+int i8q_wg_per_cu(int d) { return d == 768 ? I8qGeom<768>::WG_PER_CU : I8qGeom<128>::WG_PER_CU; }
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
 
 const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
@@ -614,12 +620,14 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	const uint32_t run = 16;
 	const uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 	const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-	uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
+	const uint32_t wg_slots = (uint32_t)i8q_wg_per_cu(h->dim) * (uint32_t)cus;
+	uint32_t chunks = std::max<uint32_t>(1, wg_slots / nqt);
 	chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 	chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
 	if (t_sel * 2 > nt || (size_t)chunks * 32 < 8 * k)
 		return kRetryGeneric;
-	const int lds = h->dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>();
+	const int lds = i8q_lds_bytes(h->dim);
+	const dim3 wg((uint32_t)i8q_threads(h->dim));
 	for (int attempt = 0;; ++attempt) {
 		rc = ensure_workspace(h, m, cap);
 		if (rc != EXPANN_OK)
@@ -658,7 +666,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			             schunks, nqt, t_sel, sp.tile_stride, sp.tiles_per_block, schunks, nt, m, sp.base,
 			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->sample_bytes);
 		mark("qself");
-		hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), dim3(kF16Threads), lds, st, sp);
+		hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), wg, lds, st, sp);
 		mark("sample");
 		SampleTauI8Params tp{};
 		tp.vals = (const int*)h->d_sample;
@@ -684,7 +692,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		fp.cap = cap;
 		uint32_t fchunks = 1;
 		{
-			const uint32_t slots = kF16WgPerCu * (uint32_t)cus;
+			const uint32_t slots = wg_slots;
 			const uint32_t gmax = std::max<uint32_t>(1, nt / 8);
 			double best = 1e300;
 			for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
@@ -702,7 +710,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		const bool timed = h->profiling && h->ev_used < kEventPairs;
 		if (timed)
 			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-		hipLaunchKernelGGL(gq->scan, dim3(fchunks * nqt), dim3(kF16Threads), lds, st, fp);
+		hipLaunchKernelGGL(gq->scan, dim3(fchunks * nqt), wg, lds, st, fp);
 		if (timed) {
 			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 			h->ev_used++;
@@ -1404,11 +1412,9 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	for (const auto& v : kGemmI8q)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>()) !=
-			        hipSuccess ||
+			                        i8q_lds_bytes(dim)) != hipSuccess ||
 			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        dim == 128 ? gemm_i8q_lds_bytes<128>() : gemm_i8q_lds_bytes<256>()) !=
-			        hipSuccess) {
+			                        i8q_lds_bytes(dim)) != hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_i8q_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;

@@ -1,8 +1,8 @@
 // scan_gemm_i8q.hpp -- the 8-bit GEMM-form filter in the geometry of scan_gemm_f16.hpp
 // (256-thread workgroups, two per CU; 64 queries x 64 rows = 2x2 MFMA tiles per wave and step;
 // LDS-DMA staging with counted vmcnt waits; per-wave hit queues in LDS; one sampled pass for the
-// threshold), on the int8 matrix cores (v_mfma_i32_32x32x32_i8), for d = 128 and 256.
-// (d = 768 keeps scan_gemm_i8.hpp: its query fragments alone are 96 VGPRs per 32 queries.)
+// threshold), on the int8 matrix cores (v_mfma_i32_32x32x32_i8), for d = 128, 256 and 768
+// (I8qGeom below: d = 768 trades the two-workgroups-per-CU layout for 8 waves on one tile).
 //
 // Integer arithmetic is exact, so the filter needs no slack and no re-rank.  Everything runs in
 // the "g domain":  g(q, b) = q.b - bp[b],  bp[b] = floor(bias[b] / 2),  bias[b] = sum b^2 (L2
@@ -63,21 +63,44 @@ __global__ __launch_bounds__(kBlock) void i8q_copy_xor_kernel(const uint32_t* in
 
 __device__ inline int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
+// Geometry by dimension.  d = 128 / 256: as scan_gemm_f16.hpp (4 waves x 64 queries, two
+// workgroups per CU, 3 tile buffers).  d = 768 (BASELINE C5): a wave's fragments of 32 queries
+// are already 96 VGPRs, so 8 waves x 32 queries share each staged tile (one workgroup per CU --
+// halving the queries per tile would double the L2->LDS traffic that bounds this shape), 2 tile
+// buffers of 48 KB, and the 16-byte chunks of a row are assigned to (k-step, lane half) in
+// natural order (2s + h), which needs 8 fragment-address registers instead of 24.
+template <int D> struct I8qGeom {
+	static constexpr int THREADS = D == 768 ? 512 : 256;
+	static constexpr int WAVES = THREADS / 64;
+	static constexpr int TQW = D == 768 ? 1 : 2;      // 32-query MFMA tiles per wave
+	static constexpr int WGQ = WAVES * 32 * TQW;      // queries per workgroup
+	static constexpr int NBUF = D == 768 ? 2 : 3;
+	static constexpr int QCAP = D == 768 ? 56 : kF16WaveQueue;  // queue entries per wave
+	static constexpr bool NATURAL = D == 768;
+	static constexpr int WG_PER_CU = 512 / THREADS;
+};
+static_assert(I8qGeom<128>::WGQ == kF16TQ && I8qGeom<768>::WGQ == kF16TQ, "one query-tile size");
+
 template <int D> constexpr int gemm_i8q_lds_bytes() {
-	return kF16Bufs * (kF16TB * D + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes +
-	       kF16TQ * 4 + 16;
+	using G = I8qGeom<D>;
+	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16;
 }
+static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<256>() * 2 <= 160 * 1024,
+              "LDS budget per CU");
 
 template <int D, bool L2FORM, bool SAMPLE>
-__global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qParams p) {
-	static_assert(D == 128 || D == 256, "built for d = 128, 256");
+__global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(GemmI8qParams p) {
+	static_assert(D == 128 || D == 256 || D == 768, "built for d = 128, 256, 768");
+	using G = I8qGeom<D>;
+	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
+	constexpr bool NATURAL = G::NATURAL;
 	constexpr int ROWB = D;          // bytes per row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
-	constexpr int KS = D / 32;       // MFMA k-steps; lane half h of k-step s holds chunk h*KS + s
+	constexpr int KS = D / 32;       // MFMA k-steps
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
-	constexpr int PF = kF16Prefetch, NBUF = kF16Bufs;
+	constexpr int NBUF = G::NBUF, PF = NBUF - 1;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const int tid = threadIdx.x;
@@ -86,8 +109,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 	const int h = lane >> 5, r31 = lane & 31;
 	const uint32_t qtile = blockIdx.x % p.n_qtiles;
 	const uint32_t chunk = blockIdx.x / p.n_qtiles;
-	const uint32_t wg_q0 = qtile * kF16TQ;
-	const uint32_t q0 = wg_q0 + wave * 64;
+	const uint32_t wg_q0 = qtile * WGQ;
+	const uint32_t q0 = wg_q0 + wave * 32 * TQW;
 
 	const uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
@@ -105,16 +128,16 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 		uint32_t pad;
 	};
 	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
-	QEntry* const queue =
-	    reinterpret_cast<QEntry*>(bn_slots + NBUF * kF16Waves * 256) + wave * kF16WaveQueue;
-	int* const thq = reinterpret_cast<int*>(bn_slots + NBUF * kF16Waves * 256 +
-	                                        kF16Waves * kF16WaveQueue * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + kF16TQ);
+	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * WAVES * 256) + wave * QCAP;
+	int* const thq =
+	    reinterpret_cast<int*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
 
 	constexpr int kNever = -2147483647 - 1;
-	i32x4 a[2][KS];
+	// query fragments; lane half h of k-step s holds chunk 2s + h (natural) or h*KS + s
+	i32x4 a[TQW][KS];
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq) {
+	for (int tq = 0; tq < TQW; ++tq) {
 		uint32_t qi = q0 + tq * 32 + r31;
 		if (qi >= p.m)
 			qi = p.m - 1;
@@ -122,60 +145,69 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 		    reinterpret_cast<const i32x4*>((const unsigned char*)p.queries + (size_t)qi * ROWB);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			a[tq][s] = src[h * KS + s];
+			a[tq][s] = src[NATURAL ? 2 * s + h : h * KS + s];
 	}
 	// accumulator start values -g_k (SAMPLE: zero starts; th holds the running class maxima)
-	i32x16 th[2];
+	i32x16 th[TQW];
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq)
+	for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 			// a padded query slot starts at INT_MIN/2: dot + that never reaches a bp >= 0
 			th[tq][reg] = SAMPLE ? kNever : (qi < p.m ? p.thp[qi] : kNever / 2);
 		}
-	if (!SAMPLE)
+	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.thp[wg_q0 + tid] : kNever / 2;
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq) {
+	for (int tq = 0; tq < TQW; ++tq) {
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
 		asm volatile("" : "+v"(th[tq]));
 	}
+	// LDS offsets of this lane's fragment chunks (row r31 of the first column tile; the second
+	// is 32 rows further, same swizzle term).  Natural order: chunk 2s + h = 16 (s >> 3) +
+	// (2 (s & 7) + h), and the XOR with the row's swizzle (< 16) only touches the low part.
 	static_assert((32 / RPB) % (SWM + 1) == 0, "swizzle must repeat every 32 rows");
-	uint32_t aoff[KS];
+	constexpr int NA = NATURAL ? 8 : KS;
+	uint32_t aoff[NA];
 #pragma unroll
-	for (int s = 0; s < KS; ++s)
-		aoff[s] = r31 * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
+	for (int j = 0; j < NA; ++j)
+		aoff[j] = r31 * ROWB + ((((NATURAL ? 2 * j + h : h * KS + j)) ^ ((r31 / RPB) & SWM)) * 16);
 
 	auto tile_row0 = [&](uint32_t t) -> uint32_t {
 		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kF16TB;
 	};
-	constexpr int ROWS_PER_INSTR = kF16Threads / CH;
-	static_assert(ROWS_PER_INSTR % (16 * RPB) == 0, "swizzle must be instruction-invariant");
-	constexpr int N_STAGE = kF16TB * CH / kF16Threads;
+	// staging: piece i of a thread is slot S = i*THREADS + tid of the tile (16 bytes each, LDS
+	// order = row-major physical chunks); its source is the logical chunk pc ^ swizzle(row)
+	constexpr int N_STAGE = kF16TB * CH / THREADS;
+	static_assert(kF16TB * CH % THREADS == 0, "whole staging rounds");
 	constexpr int LOADS = N_STAGE + 1;
-	const uint32_t lane_row = tid / CH;
-	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
+	uint32_t soff[N_STAGE];
+#pragma unroll
+	for (int i = 0; i < N_STAGE; ++i) {
+		const uint32_t S = i * THREADS + tid;
+		const uint32_t r = S / CH, pc = S % CH;
+		soff[i] = r * ROWB + ((pc ^ ((r / RPB) & SWM)) * 16);
+	}
 	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
 		if (i < N_STAGE) {
 			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
 			__builtin_amdgcn_global_load_lds(
-			    (const __attribute__((address_space(1))) void*)(tb + (uint32_t)i * ROWS_PER_INSTR * ROWB),
-			    (__attribute__((address_space(3))) void*)(dst0 + i * kF16Threads * 16), 16, 0, 0);
+			    (const __attribute__((address_space(1))) void*)(tb + soff[i < N_STAGE ? i : 0]),
+			    (__attribute__((address_space(3))) void*)(dst0 + i * THREADS * 16), 16, 0, 0);
 		} else {
 			__builtin_amdgcn_global_load_lds(
 			    (const __attribute__((address_space(1))) void*)(p.bp + row0 + lane),
-			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0,
-			    0);
+			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * WAVES + wave) * 256), 4, 0, 0);
 		}
 	};
 	auto stage_src = [&](uint32_t t, uint32_t& row0) -> const unsigned char* {
 		if (t > t1 - 1)
 			t = t1 - 1;
 		row0 = tile_row0(t);
-		return (const unsigned char*)p.base + (size_t)row0 * ROWB + lane_off;
+		return (const unsigned char*)p.base + (size_t)row0 * ROWB;
 	};
 	auto stage = [&](uint32_t t, int buf) {
 		uint32_t row0;
@@ -185,7 +217,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 			stage_piece(tb, row0, buf, i);
 	};
 	auto read_bp = [&](int (&bv)[2], int buf) {
-		const int* slot = reinterpret_cast<const int*>(bn_slots + (buf * kF16Waves + wave) * 256);
+		const int* slot = reinterpret_cast<const int*>(bn_slots + (buf * WAVES + wave) * 256);
 		bv[0] = slot[r31];
 		bv[1] = slot[32 + r31];
 	};
@@ -193,14 +225,14 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 	uint32_t wfill = 0;  // wave-uniform
 	auto push_global = [&](uint32_t qi, int acc, uint32_t row) {
 		// exact integer score from the accumulator: dot = acc - thp[q]
-		const int dot = acc - thq[(qi - wg_q0) & (kF16TQ - 1)];
+		const int dot = acc - thq[(qi - wg_q0) & (WGQ - 1)];
 		const int score = L2FORM ? p.bias[row] - 2 * dot + p.qself[qi] : -dot;
 		const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
 		if (slot < p.cap)
 			p.cand[(size_t)qi * p.cap + slot] = make_key((float)score, row);
 	};
 	auto flush_own = [&]() {
-		const uint32_t n = wfill < (uint32_t)kF16WaveQueue ? wfill : (uint32_t)kF16WaveQueue;
+		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		constexpr int R = 4;
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 				row[j] = e.row;
 				hit[j] = i < n * 16 && c >= e.bp && row[j] < p.n_rows;
 				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
-				dot[j] = c - thq[(qi[j] - wg_q0) & (kF16TQ - 1)];
+				dot[j] = c - thq[(qi[j] - wg_q0) & (WGQ - 1)];
 			}
 			int score[R];
 #pragma unroll
@@ -231,9 +263,9 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 		}
 		wfill = 0;
 	};
-	auto epilogue = [&](const i32x16 (&accs)[2][2], uint32_t row0, const int (&bv)[2]) {
+	auto epilogue = [&](const i32x16 (&accs)[TQW][2], uint32_t row0, const int (&bv)[2]) {
 #pragma unroll
-		for (int tq = 0; tq < 2; ++tq)
+		for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 			for (int tc = 0; tc < 2; ++tc) {
 				const i32x16& c = accs[tq][tc];
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 					    wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
 					                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 					if (m0 >= bn) {
-						if (slot < (uint32_t)kF16WaveQueue) {
+						if (slot < (uint32_t)QCAP) {
 							QEntry& e = queue[slot];
 #pragma unroll
 							for (int reg = 0; reg < 16; ++reg)
@@ -285,7 +317,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 		stage(t0 + i, i);
 	wait_vm_then_barrier<(PF - 1) * LOADS>();
 
-	i32x16 acc[2][2];
+	i32x16 acc[TQW][2];
 	i32x16 zero16;
 #pragma unroll
 	for (int e = 0; e < 16; ++e)
@@ -296,7 +328,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 	for (uint32_t t = t0; t < t1; ++t) {
 		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int tc, int s) -> i32x4 {
-			return *reinterpret_cast<const i32x4*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
+			const uint32_t o = NATURAL ? aoff[s & 7] + (s >> 3) * 256 : aoff[NATURAL ? 0 : s];
+			return *reinterpret_cast<const i32x4*>(smem + (boff + o) + tc * 32 * ROWB);
 		};
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
@@ -314,13 +347,13 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 				fb[s + 2][1] = frag(1, s + 2);
 			}
 #pragma unroll
-			for (int tq = 0; tq < 2; ++tq) {
+			for (int tq = 0; tq < TQW; ++tq) {
 				acc[tq][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
 				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
 				acc[tq][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
 				    a[tq][s], fb[s][1], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
 			}
-			// the stage loads of tile t+PF go out between the MFMAs (LOADS may exceed KS at d = 256)
+			// the stage loads of tile t+PF go out between the MFMAs
 			constexpr int PER = (LOADS + KS - 1) / KS;
 #pragma unroll
 			for (int j = 0; j < PER; ++j)
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 		}
 		if (SAMPLE) {
 #pragma unroll
-			for (int tq = 0; tq < 2; ++tq)
+			for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 				for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
@@ -345,8 +378,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 			wait_vm_then_barrier<(PF - 1) * LOADS>();
 			if (look) {
 				since_look = 0;
-				const uint32_t f = fills[lane & (kF16Waves - 1)];
-				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)kF16WaveQueue / 2) != 0)
+				const uint32_t f = fills[lane & (WAVES - 1)];
+				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
 					flush_own();
 			}
 		}
@@ -355,7 +388,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_i8q_kernel(GemmI8qPa
 	}
 	if (SAMPLE) {
 #pragma unroll
-		for (int tq = 0; tq < 2; ++tq)
+		for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 			for (int reg = 0; reg < 16; ++reg) {
 				const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;

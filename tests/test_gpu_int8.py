@@ -139,6 +139,7 @@ def test_gemm_form_int8_mfma(oracle, dtype, metric, ometric, d, n, m, k):
     ("u8", "l2", "METRIC_L2_U8", 128), ("u8", "l2", "METRIC_L2_U8", 256),
     ("i8", "l2", "METRIC_L2_I8", 128), ("i8", "ip", "METRIC_IP_I8", 128),
     ("i8", "l2", "METRIC_L2_I8", 256), ("i8", "ip", "METRIC_IP_I8", 256),
+    ("i8", "ip", "METRIC_IP_I8", 768), ("i8", "l2", "METRIC_L2_I8", 768), ("u8", "l2", "METRIC_L2_U8", 768),
 ])
 @pytest.mark.parametrize("n,m,k", [(40000, 130, 10), (70001, 300, 17), (65536, 97, 100)])
 def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
