@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-ratio", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sample-run", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--clustered", type=int, default=0,
+                    help="synthetic base = this many Gaussian clusters stored contiguously (robustness "
+                         "probe; default 0 = iid rows)")
     ap.add_argument("--scan-kernel", type=int, default=0,
                     help="0 auto, 1 direct, 2 GEMM form fp32/int8 MFMA, 3 GEMM form bf16x3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -244,6 +248,13 @@ def main():
         base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
         g.manual_seed(4321)
         queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
+        if a.clustered and G == 1:
+            # rows sorted by cluster: centres N(0, 1), members centre + 0.3 N(0, 1); queries near centres
+            centres = torch.randn(a.clustered, a.d, device=dev, generator=g)
+            per = (a.n + a.clustered - 1) // a.clustered
+            base = base.mul_(0.3).add_(centres.repeat_interleave(per, 0)[:a.n])
+            pick = torch.randint(0, a.clustered, (a.m,), device=dev, generator=g)
+            queries = queries.mul_(0.3).add_(centres[pick])
     elif a.dtype == "i8":   # int8 uniform in [-127, 127]
         base = torch.randint(-127, 128, (hi - lo, a.d), device=dev, dtype=torch.int8, generator=g)
         g.manual_seed(4321)
@@ -267,6 +278,8 @@ def main():
         eng.set_option("sample_ratio", a.sample_ratio)
     if a.sample_frac:
         eng.set_option("sample_frac", a.sample_frac)
+    if a.sample_run:
+        eng.set_option("sample_run", a.sample_run)
     ids = torch.full((pad, a.k), -1, dtype=torch.int64, device=dev)      # rows past the slice stay
     dists = torch.full((pad, a.k), float("inf"), dtype=torch.float32, device=dev)  # padding
     out_ids = torch.empty_like(ids)
