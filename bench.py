@@ -280,28 +280,30 @@ def main():
         eng.set_option("sample_frac", a.sample_frac)
     if a.sample_run:
         eng.set_option("sample_run", a.sample_run)
-    ids = torch.full((pad, a.k), -1, dtype=torch.int64, device=dev)      # rows past the slice stay
-    dists = torch.full((pad, a.k), float("inf"), dtype=torch.float32, device=dev)  # padding
-    out_ids = torch.empty_like(ids)
-    out_d = torch.empty_like(dists)
+    from expann_amd.sharded import GridShardedSearch, chunk_bytes, unpack_chunk
+    from expann_amd import merge_topk_strided_device
     bufs = {}
     stream = torch.cuda.current_stream().cuda_stream
+    cb = chunk_bytes(pad, a.k)
 
-    def local_search(q, k):
-        eng.search_device(q.data_ptr(), q.shape[0], k, ids.data_ptr(), dists.data_ptr(), stream)
-        return ids, dists
-
-    def merge(all_ids, all_d):
-        merge_topk_device(local_rank, all_ids.data_ptr(), all_d.data_ptr(), all_ids.shape[0], pad, a.k,
-                          out_ids.data_ptr(), out_d.data_ptr(), stream)
-        return out_ids, out_d
-
-    def alloc(name, shape, like):
+    def alloc(name, nbytes, like):
         if name not in bufs:
-            bufs[name] = torch.empty(shape, dtype=like.dtype, device=dev)
+            bufs[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if name == "mine":      # rows past this rank's query slice stay padding for good
+                pi, pd = unpack_chunk(bufs[name], pad, a.k)
+                pi.fill_(-1)
+                pd.fill_(float("inf"))
         return bufs[name]
 
-    from expann_amd.sharded import GridShardedSearch
+    def local_search(q, k, chunk):
+        base_ptr = chunk.data_ptr()
+        eng.search_device(q.data_ptr(), q.shape[0], k, base_ptr, base_ptr + pad * k * 8, stream)
+
+    def merge(gathered, n_lists, rows, k, out_chunk):
+        gp, op = gathered.data_ptr(), out_chunk.data_ptr()
+        merge_topk_strided_device(local_rank, gp, gp + rows * k * 8, cb // 8, cb // 4, n_lists, rows, k,
+                                  op, op + rows * k * 8, stream)
+
     ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
 
     def step():

@@ -1654,9 +1654,9 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 	return EXPANN_OK;
 }
 
-int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
-                             size_t n_lists, size_t m, size_t k, uint64_t* d_out_ids,
-                             float* d_out_dists, void* stream) {
+int expann_merge_topk_strided_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
+                                     size_t ids_stride, size_t dists_stride, size_t n_lists, size_t m,
+                                     size_t k, uint64_t* d_out_ids, float* d_out_dists, void* stream) {
 	if (!d_in_ids || !d_in_dists || !d_out_ids || !d_out_dists || n_lists == 0 || n_lists > 64 ||
 	    k == 0) {
 		g_create_error = "expann_merge_topk_device: bad arguments (1 <= n_lists <= 64)";
@@ -1669,13 +1669,20 @@ int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* 
 		return EXPANN_ERR_HIP;
 	}
 	hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
-	                   dim3(kBlock), 0, (hipStream_t)stream, d_in_ids, d_in_dists,
-	                   (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids, d_out_dists);
+	                   dim3(kBlock), 0, (hipStream_t)stream, d_in_ids, d_in_dists, ids_stride,
+	                   dists_stride, (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids, d_out_dists);
 	if (hipGetLastError() != hipSuccess) {
 		g_create_error = "merge_topk_kernel launch failed";
 		return EXPANN_ERR_HIP;
 	}
 	return EXPANN_OK;
+}
+
+int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
+                             size_t n_lists, size_t m, size_t k, uint64_t* d_out_ids,
+                             float* d_out_dists, void* stream) {
+	return expann_merge_topk_strided_device(device, d_in_ids, d_in_dists, m * k, m * k, n_lists, m, k,
+	                                        d_out_ids, d_out_dists, stream);
 }
 
 int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, size_t n_ids,

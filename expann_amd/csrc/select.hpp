@@ -512,8 +512,11 @@ __global__ __launch_bounds__(1024) void max_f32_kernel(const float* in, size_t n
 
 // k-way merge of n_lists ascending (score, id) lists per query; one thread per query.
 // Lists are padded with (+inf, UINT64_MAX).  Order: score, then id (64-bit).
+// List g starts at in_ids + g*ids_stride / in_dists + g*dists_stride (elements): m*k each for
+// separate [n_lists][m][k] arrays, or the chunk size when every rank's chunk is [ids | dists].
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const uint64_t* in_ids,
                                                             const float* in_dists,
+                                                            size_t ids_stride, size_t dists_stride,
                                                             uint32_t n_lists, uint32_t m,
                                                             uint32_t k, uint64_t* out_ids,
                                                             float* out_dists) {
@@ -531,11 +534,11 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const uint64_t* in_i
 		for (uint32_t g = 0; g < n_lists; ++g) {
 			if (pos[g] >= k)
 				continue;
-			const size_t off = ((size_t)g * m + qi) * k + pos[g];
-			const uint64_t id = in_ids[off];
+			const size_t off = (size_t)qi * k + pos[g];
+			const uint64_t id = in_ids[g * ids_stride + off];
 			if (id == ~0ull)
 				continue;  // padding: this list is exhausted
-			const uint32_t o = float_to_ordered(in_dists[off]);
+			const uint32_t o = float_to_ordered(in_dists[g * dists_stride + off]);
 			if (best == n_lists || o < bo || (o == bo && id < bid)) {
 				best = g;
 				bo = o;

@@ -121,6 +121,18 @@ class GpuBruteForceEngine:
             pass
 
 
+def merge_topk_strided_device(device, in_ids_ptr, in_dists_ptr, ids_stride, dists_stride, n_lists, m,
+                              k, out_ids_ptr, out_dists_ptr, stream=0):
+    """expann_merge_topk_strided_device: list g at in_ids + g*ids_stride / in_dists + g*dists_stride
+    (strides in elements)."""
+    L = _lib.load()
+    rc = L.expann_merge_topk_strided_device(device, C.c_void_p(in_ids_ptr), C.c_void_p(in_dists_ptr),
+                                            ids_stride, dists_stride, n_lists, m, k,
+                                            C.c_void_p(out_ids_ptr), C.c_void_p(out_dists_ptr),
+                                            C.c_void_p(stream))
+    _lib.check(None, rc)
+
+
 def merge_topk_device(device, in_ids_ptr, in_dists_ptr, n_lists, m, k, out_ids_ptr,
                       out_dists_ptr, stream=0):
     L = _lib.load()

@@ -55,19 +55,34 @@ def shard_grid(world, row_shards=None):
     return row_shards, world // row_shards
 
 
+def chunk_bytes(rows, k):
+    """bytes of one rank's exchange chunk: [ids: rows*k uint64 | dists: rows*k fp32], padded to 16."""
+    return (rows * k * 12 + 15) // 16 * 16
+
+
+def unpack_chunk(chunk, rows, k):
+    """(ids[rows,k] int64 view, dists[rows,k] float32 view) of a uint8 chunk tensor."""
+    import torch
+    ids = chunk[:rows * k * 8].view(torch.int64).view(rows, k)
+    dists = chunk[rows * k * 8:rows * k * 12].view(torch.float32).view(rows, k)
+    return ids, dists
+
+
 class GridShardedSearch:
     """rank r = query group (r // R) x row shard (r % R), R = row shards.
 
-    search(): (1) every rank scans ITS rows for ITS query slice (no collective), (2) the R ranks
-    of a query group all-gather their [m_slice][k] lists and merge them (as ShardedSearch),
-    (3) the merged slices are all-gathered across the query groups, so every rank ends with the
-    full [m][k] result.  Slices are padded to ceil(m / groups) queries for the fixed-size
-    collectives."""
+    search(): (1) every rank scans ITS rows for ITS query slice (no collective) and leaves the
+    [slice][k] ids and distances in ONE chunk `[ids | dists]`; (2) the R ranks of a query group
+    all-gather their chunks (one collective) and merge them (expann_merge_topk_strided_device
+    reads the lists where they landed); (3) the merged chunks are all-gathered across the query
+    groups (one collective), so every rank ends with the full [m][k] result.  Slices are padded
+    to ceil(m / groups) queries for the fixed-size collectives."""
 
     def __init__(self, dist, world, rank, row_shards, local_search, merge, alloc):
-        """local_search(queries_slice, k) -> (ids[ms,k], dists[ms,k]) of this rank's rows
-        (global ids), written into buffers with room for `pad` rows; merge(all_ids[R,ms,k],
-        all_d[R,ms,k]) -> (ids[ms,k], dists[ms,k]); alloc(name, shape, like) -> cached tensor."""
+        """local_search(queries_slice, k, chunk): this rank's rows, results (global ids) into the
+        uint8 chunk (rows beyond the slice keep their padding); merge(gathered, n_lists, rows, k,
+        out_chunk): `gathered` holds n_lists chunks back to back; alloc(name, nbytes, like) ->
+        cached uint8 tensor on like's device."""
         self.dist, self.world, self.rank = dist, world, rank
         self.R, self.Q = shard_grid(world, row_shards)
         self.row_idx, self.qgroup = rank % self.R, rank // self.R
@@ -88,29 +103,26 @@ class GridShardedSearch:
         return shard_range(m, self.qgroup, self.Q)
 
     def search(self, queries, k):
+        import torch
         m = queries.shape[0]
         lo, hi = self.query_slice(m)
         pad = (m + self.Q - 1) // self.Q
-        ids, dists = self.local_search(queries[lo:hi], k)
-        if self.world == 1:
-            return ids, dists
+        cb = chunk_bytes(pad, k)
+        mine = self.alloc("mine", cb, queries)
+        self.local_search(queries[lo:hi], k, mine)
         if self.R > 1:
-            all_ids = self.alloc("row_ids", (self.R * ids.shape[0],) + tuple(ids.shape[1:]), ids)
-            all_d = self.alloc("row_d", (self.R * dists.shape[0],) + tuple(dists.shape[1:]), dists)
-            self.dist.all_gather_into_tensor(all_ids, ids, group=self.row_group)
-            self.dist.all_gather_into_tensor(all_d, dists, group=self.row_group)
-            ids, dists = self.merge(all_ids.view(self.R, *ids.shape), all_d.view(self.R, *dists.shape))
+            gathered = self.alloc("row_gather", self.R * cb, queries)
+            self.dist.all_gather_into_tensor(gathered, mine, group=self.row_group)
+            merged = self.alloc("merged", cb, queries)
+            self.merge(gathered, self.R, pad, k, merged)
+            mine = merged
         if self.Q == 1:
+            ids, dists = unpack_chunk(mine, pad, k)
             return ids[:m], dists[:m]
-        assert ids.shape[0] == pad, "local_search / merge must return the padded slice"
-        full_ids = self.alloc("full_ids", (self.Q * pad,) + tuple(ids.shape[1:]), ids)
-        full_d = self.alloc("full_d", (self.Q * pad,) + tuple(dists.shape[1:]), dists)
-        self.dist.all_gather_into_tensor(full_ids, ids, group=self.col_group)
-        self.dist.all_gather_into_tensor(full_d, dists, group=self.col_group)
-        if m == self.Q * pad:
-            return full_ids, full_d
-        import torch
+        full = self.alloc("full", self.Q * cb, queries)
+        self.dist.all_gather_into_tensor(full, mine, group=self.col_group)
         parts = [shard_range(m, g, self.Q) for g in range(self.Q)]
-        keep_i = [full_ids[g * pad:g * pad + (b - a)] for g, (a, b) in enumerate(parts)]
-        keep_d = [full_d[g * pad:g * pad + (b - a)] for g, (a, b) in enumerate(parts)]
-        return torch.cat(keep_i, 0), torch.cat(keep_d, 0)
+        views = [unpack_chunk(full[g * cb:(g + 1) * cb], pad, k) for g in range(self.Q)]
+        ids = torch.cat([v[0][:b - a] for v, (a, b) in zip(views, parts)], 0)
+        dists = torch.cat([v[1][:b - a] for v, (a, b) in zip(views, parts)], 0)
+        return ids, dists

@@ -102,6 +102,13 @@ int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* 
                              size_t n_lists, size_t m, size_t k, uint64_t* d_out_ids,
                              float* d_out_dists, void* stream);
 
+/* the same with explicit distances (in elements) between the lists: list g is at
+ * d_in_ids + g*ids_stride and d_in_dists + g*dists_stride.  For all-gathered chunks that hold
+ * [ids | dists] of one rank each (one collective per exchange instead of two). */
+int expann_merge_topk_strided_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
+                                     size_t ids_stride, size_t dists_stride, size_t n_lists, size_t m,
+                                     size_t k, uint64_t* d_out_ids, float* d_out_dists, void* stream);
+
 /* batched candidate scoring (quantized_scorer::filter_by_score, src/quantizer.h:20-59):
  * for each of n_ids row ids (order kept) score against ONE query; keep (id, score) with
  * score < cutoff.  Host buffers; *n_kept receives the count. */

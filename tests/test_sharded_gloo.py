@@ -89,23 +89,31 @@ def _grid_worker(rank, world, row_shards, port, n, d, m, k, out):
     lo, hi = shard_range(n, rank % R, R)
     pad = (m + Q - 1) // Q
     bufs = {}
+    from expann_amd.sharded import unpack_chunk, chunk_bytes
 
-    def alloc(name, shape, like):
+    def alloc(name, nbytes, like):
         if name not in bufs:
-            bufs[name] = torch.empty(shape, dtype=like.dtype)
+            bufs[name] = torch.zeros(nbytes, dtype=torch.uint8)
         return bufs[name]
 
-    def local_search(q, kk):
-        ids = np.full((pad, kk), np.uint64(2 ** 64 - 1), np.uint64)
-        dd = np.full((pad, kk), np.inf, np.float32)
+    def local_search(q, kk, chunk):
+        ids_v, d_v = unpack_chunk(chunk, pad, kk)
+        ids_v.fill_(-1)
+        d_v.fill_(float("inf"))
         i, x = oc.brute_force(base[lo:hi], q.numpy(), kk)
-        ids[:len(i)] = np.where(i == np.uint64(2 ** 64 - 1), i, i + np.uint64(lo))
-        dd[:len(i)] = x
-        return torch.from_numpy(ids.view(np.int64)), torch.from_numpy(dd)
+        i = np.where(i == np.uint64(2 ** 64 - 1), i, i + np.uint64(lo))
+        ids_v[:len(i)] = torch.from_numpy(i.view(np.int64))
+        d_v[:len(i)] = torch.from_numpy(x)
 
-    def merge(all_ids, all_d):
-        i, dd = _merge_np(all_ids.numpy(), all_d.numpy())
-        return torch.from_numpy(i), torch.from_numpy(dd)
+    def merge(gathered, n_lists, rows, kk, out_chunk):
+        cb = chunk_bytes(rows, kk)
+        lists = [unpack_chunk(gathered[g * cb:(g + 1) * cb], rows, kk) for g in range(n_lists)]
+        all_ids = np.stack([l[0].numpy() for l in lists], 0)
+        all_d = np.stack([l[1].numpy() for l in lists], 0)
+        i, dd = _merge_np(all_ids, all_d)
+        oi, od = unpack_chunk(out_chunk, rows, kk)
+        oi.copy_(torch.from_numpy(i))
+        od.copy_(torch.from_numpy(dd))
 
     gs = GridShardedSearch(dist, world, rank, row_shards, local_search, merge, alloc)
     ids, dd = gs.search(torch.from_numpy(queries), k)
