@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libexpann_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_BUILT, ERR_UNSUPPORTED, ERR_OVERFLOW = 1, 2, 3, 4, 5, 6
-DTYPE_F32, DTYPE_U8, DTYPE_I8 = 0, 1, 2
+DTYPE_F32, DTYPE_U8, DTYPE_I8, DTYPE_I16 = 0, 1, 2, 3
 METRIC_L2, METRIC_IP, METRIC_L2_I8_REFCOMPAT = 0, 1, 2
 
 # every symbol include/expann_hip.h declares

@@ -204,9 +204,15 @@ struct ScanI8Variant {
 #define SCAN_I8_M(D, TQ, MODE, MN) {D, TQ, MODE, scan_filter_i8_kernel<D, TQ, MODE>, "scan_filter_i8<" #D "," #TQ "," MN ">"}
 #define SCAN_I8(D, TQ) SCAN_I8_M(D, TQ, kU8L2, "U8L2"), SCAN_I8_M(D, TQ, kI8L2, "I8L2"), \
 	SCAN_I8_M(D, TQ, kI8L2Ref, "I8L2REF"), SCAN_I8_M(D, TQ, kI8IP, "I8IP")
+// int16 rows: d ELEMENTS, kernels instantiated on 2 d bytes per row
+#define SCAN_I16(DE, TQ) {DE, TQ, kI16L2Ref, scan_filter_i8_kernel<2 * DE, TQ, kI16L2Ref>, \
+	"scan_filter_i16<" #DE "," #TQ ",L2REF>"}
 const ScanI8Variant kScanI8[] = {SCAN_I8(64, 1),  SCAN_I8(64, 16), SCAN_I8(128, 1), SCAN_I8(128, 4),
                                  SCAN_I8(128, 16), SCAN_I8(256, 1), SCAN_I8(256, 8), SCAN_I8(768, 1),
-                                 SCAN_I8(768, 4),  SCAN_I8(768, 8), SCAN_I8(960, 1), SCAN_I8(960, 4)};
+                                 SCAN_I8(768, 4),  SCAN_I8(768, 8), SCAN_I8(960, 1), SCAN_I8(960, 4),
+                                 SCAN_I16(64, 1),  SCAN_I16(64, 4), SCAN_I16(64, 16), SCAN_I16(128, 1),
+                                 SCAN_I16(128, 8)};
+#undef SCAN_I16
 #undef SCAN_I8
 #undef SCAN_I8_M
 
@@ -240,7 +246,9 @@ struct ScoreI8Variant {
 };
 #define SCORE_I8(D) {D, kU8L2, score_ids_i8_kernel<D, kU8L2>}, {D, kI8L2, score_ids_i8_kernel<D, kI8L2>}, \
 	{D, kI8L2Ref, score_ids_i8_kernel<D, kI8L2Ref>}, {D, kI8IP, score_ids_i8_kernel<D, kI8IP>}
-const ScoreI8Variant kScoreI8[] = {SCORE_I8(64), SCORE_I8(128), SCORE_I8(256), SCORE_I8(768), SCORE_I8(960)};
+const ScoreI8Variant kScoreI8[] = {SCORE_I8(64), SCORE_I8(128), SCORE_I8(256), SCORE_I8(768), SCORE_I8(960),
+                                   {64, kI16L2Ref, score_ids_i8_kernel<128, kI16L2Ref>},
+                                   {128, kI16L2Ref, score_ids_i8_kernel<256, kI16L2Ref>}};
 #undef SCORE_I8
 
 uint32_t pow2ceil(uint32_t x) {
@@ -1345,6 +1353,12 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 			return EXPANN_ERR_INVALID_ARG;
 		}
 		int_mode = kU8L2;
+	} else if (dtype == EXPANN_DTYPE_I16) {
+		if (metric != EXPANN_METRIC_L2) {
+			g_create_error = "int16 rows support EXPANN_METRIC_L2 only (src/distance.h:14-27 semantics)";
+			return EXPANN_ERR_INVALID_ARG;
+		}
+		int_mode = kI16L2Ref;
 	} else if (dtype == EXPANN_DTYPE_I8) {
 		if (metric == EXPANN_METRIC_L2)
 			int_mode = kI8L2;
@@ -1384,8 +1398,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	h->dtype = dtype;
 	h->metric = metric;
 	h->device = device;
-	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : 1;
-	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : 4;
+	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : (dtype == EXPANN_DTYPE_I16 ? 2 : 1);
+	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : (dtype == EXPANN_DTYPE_I16 ? 2 : 4);
 	h->int_mode = int_mode;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";

@@ -21,7 +21,11 @@
 
 namespace expann {
 
-enum IntMode : int { kU8L2 = 0, kI8L2 = 1, kI8L2Ref = 2, kI8IP = 3 };
+// kI16L2Ref: int16 rows, src/distance.h:14-27 bit for bit (distance_compare_avx512f_i32): 16-bit
+// wrapping subtract, mullo_epi16 keeps the low 16 bits of the square, madd_epi16 with 1
+// sign-extends it and adds -- so a term is wrong once |a_i - b_i| > 181, as in the reference.
+// The kernels below are instantiated with D = BYTES per row (2 x the element count).
+enum IntMode : int { kU8L2 = 0, kI8L2 = 1, kI8L2Ref = 2, kI8IP = 3, kI16L2Ref = 4 };
 
 template <int MODE> __device__ inline int dot4(int a, int b, int c) {
 	if (MODE == kU8L2 || MODE == kI8L2Ref)
@@ -36,6 +40,14 @@ __device__ inline int sub_bytes(int a, int b) {
 	return (int)(d ^ ((ua ^ ~ub) & 0x80808080u));
 }
 
+// (a - b) and (d * d) on two packed int16, low 16 bits each (v_pk_sub_i16 / v_pk_mul_lo_u16)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ inline int i16_refcompat_term(int a, int b) {
+	const s16x2 d = __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b);
+	const s16x2 sq = d * d;
+	return (int)sq.x + (int)sq.y;  // sign-extended, as madd_epi16(1, sq)
+}
+
 // the integer score of one (query, row) pair restricted to this lane's dwords; the caller
 // reduces over the 16 lanes and adds the query-only term
 template <int MODE, int NW>
@@ -43,7 +55,9 @@ __device__ inline int partial_score(const int (&q)[NW], const int (&b)[NW], int 
 	int acc = 0;
 #pragma unroll
 	for (int w = 0; w < NW; ++w) {
-		if (MODE == kI8L2Ref) {
+		if (MODE == kI16L2Ref) {
+			acc += i16_refcompat_term(q[w], b[w]);
+		} else if (MODE == kI8L2Ref) {
 			const int d = sub_bytes(q[w], b[w]);
 			acc = dot4<MODE>(d, d, acc);
 		} else {

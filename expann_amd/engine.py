@@ -13,7 +13,8 @@ import numpy as np
 
 from . import _lib
 
-_NP_DTYPE = {_lib.DTYPE_F32: np.float32, _lib.DTYPE_U8: np.uint8, _lib.DTYPE_I8: np.int8}
+_NP_DTYPE = {_lib.DTYPE_F32: np.float32, _lib.DTYPE_U8: np.uint8, _lib.DTYPE_I8: np.int8,
+             _lib.DTYPE_I16: np.int16}
 
 
 class GpuBruteForceEngine:
@@ -24,7 +25,8 @@ class GpuBruteForceEngine:
         self.dim = int(dim)
         self.metric = {"l2": _lib.METRIC_L2, "ip": _lib.METRIC_IP,
                        "l2_i8_refcompat": _lib.METRIC_L2_I8_REFCOMPAT}[metric]
-        self.dtype = {"f32": _lib.DTYPE_F32, "u8": _lib.DTYPE_U8, "i8": _lib.DTYPE_I8}[dtype]
+        self.dtype = {"f32": _lib.DTYPE_F32, "u8": _lib.DTYPE_U8, "i8": _lib.DTYPE_I8,
+                      "i16": _lib.DTYPE_I16}[dtype]
         self.device = int(device)
         self._metric_name, self._dtype_name = metric, dtype
         h = C.c_void_p()
@@ -62,7 +64,7 @@ class GpuBruteForceEngine:
     # ---- extensions ---------------------------------------------------------------
     def query_k_batch(self, queries, k):
         """(ids[m,k] uint64, dists[m,k] float32); short rows padded with 2^64-1 / +inf."""
-        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else np.int8
+        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else _NP_DTYPE[self.dtype]
         queries = np.ascontiguousarray(queries, dtype=qdt)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise ValueError(f"queries must be [m, {self.dim}]")
@@ -83,7 +85,7 @@ class GpuBruteForceEngine:
 
     def score_ids(self, query, ids, cutoff=float("inf")):
         """quantized_scorer::filter_by_score (src/quantizer.h:20-59): (kept_ids, kept_scores)."""
-        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else np.int8
+        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else _NP_DTYPE[self.dtype]
         query = np.ascontiguousarray(query, dtype=qdt)
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         kept = np.empty(ids.size, dtype=np.uint64)

@@ -39,7 +39,11 @@ enum expann_status {
 enum expann_dtype {
 	EXPANN_DTYPE_F32 = 0, /* vec<float> rows, src/vec.h:17-23                         */
 	EXPANN_DTYPE_U8 = 1,  /* quantizer_simple<uint8_t> rows, src/quantizer.h:127      */
-	EXPANN_DTYPE_I8 = 2   /* quantizer_ranged_q8 rows, src/quantizer.h:152-238        */
+	EXPANN_DTYPE_I8 = 2,  /* quantizer_ranged_q8 rows, src/quantizer.h:152-238        */
+	EXPANN_DTYPE_I16 = 3  /* int16 rows scored by src/distance.h:14-27 bit for bit
+	                       * (distance_compare_avx512f_i32: 16-bit wrapping arithmetic,
+	                       * exact only while |a_i - b_i| <= 181); EXPANN_METRIC_L2 only,
+	                       * dim 64 or 128; queries int16                            */
 };
 
 /* how a (query, row) pair is scored; smaller score = nearer */

@@ -296,6 +296,8 @@ static size_t elem_size(int metric) {
 	case ORACLE_METRIC_L2_F32:
 	case ORACLE_METRIC_IP_F32:
 		return 4;
+	case ORACLE_METRIC_L2_I16_REFCOMPAT:
+		return 2;
 	default:
 		return 1;
 	}
@@ -318,6 +320,8 @@ static inline float score_row(const void* base, size_t row, size_t d, const void
 	case ORACLE_METRIC_L2_U8:
 		return (float)oracle_l2_u8_compressed((const float*)q,
 		                                      (const uint8_t*)base + row * d, d);
+	case ORACLE_METRIC_L2_I16_REFCOMPAT:
+		return (float)oracle_l2_i16_refcompat((const int16_t*)q, (const int16_t*)base + row * d, d);
 	}
 	return NAN;
 }

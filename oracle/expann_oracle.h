@@ -102,7 +102,8 @@ enum {
 	ORACLE_METRIC_L2_I8 = 2,            /* oracle_l2_i8                               */
 	ORACLE_METRIC_L2_I8_REFCOMPAT = 3,  /* oracle_l2_i8_refcompat                     */
 	ORACLE_METRIC_IP_I8 = 4,            /* -oracle_ip_i8                              */
-	ORACLE_METRIC_L2_U8 = 5             /* oracle_l2_u8_compressed (fp32 query)       */
+	ORACLE_METRIC_L2_U8 = 5,            /* oracle_l2_u8_compressed (fp32 query)       */
+	ORACLE_METRIC_L2_I16_REFCOMPAT = 6  /* oracle_l2_i16_refcompat (int16 rows)       */
 };
 
 /* src/brute_force_engine.h:28-46 _query_k over a dense row-major base (the layout of

@@ -17,6 +17,7 @@ METRIC_L2_I8 = 2
 METRIC_L2_I8_REFCOMPAT = 3
 METRIC_IP_I8 = 4
 METRIC_L2_U8 = 5
+METRIC_L2_I16_REFCOMPAT = 6
 
 _f32p = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)
@@ -133,7 +134,8 @@ def _ptr(a):
 
 
 _BASE_DT = {METRIC_L2_F32: np.float32, METRIC_IP_F32: np.float32, METRIC_L2_I8: np.int8,
-            METRIC_L2_I8_REFCOMPAT: np.int8, METRIC_IP_I8: np.int8, METRIC_L2_U8: np.uint8}
+            METRIC_L2_I8_REFCOMPAT: np.int8, METRIC_IP_I8: np.int8, METRIC_L2_U8: np.uint8,
+            METRIC_L2_I16_REFCOMPAT: np.int16}
 _Q_DT = dict(_BASE_DT)
 _Q_DT[METRIC_L2_U8] = np.float32
 

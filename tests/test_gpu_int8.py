@@ -162,6 +162,29 @@ def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,m,k,spread", [(20000, 128, 40, 10, 90), (4099, 64, 7, 17, 90),
+                                             (3000, 128, 20, 10, 20000)])
+def test_int16_rows_refcompat(oracle, n, d, m, k, spread):
+    """int16 rows with the arithmetic of src/distance.h:14-27 (16-bit wrapping
+    subtract and square, sign-extended sum).  spread 90: |a-b| <= 180, where it equals the true
+    L2; spread 20000: differences far beyond 181, where the reference's value is garbage --
+    and the GPU must reproduce exactly that garbage, ties by row number included."""
+    rng = np.random.RandomState(n + d)
+    base = rng.randint(-spread, spread + 1, size=(n, d)).astype(np.int16)
+    queries = rng.randint(-spread, spread + 1, size=(m, d)).astype(np.int16)
+    eng = _engine(base, "l2", "i16")
+    _check(oracle, eng, base, queries, k, oracle.METRIC_L2_I16_REFCOMPAT)
+    if spread <= 90:   # no wrap: also the true squared L2
+        ids, dists = eng.query_k_batch(queries[:3], 1)
+        want = ((base[ids[:, 0].astype(np.int64)].astype(np.int64) - queries[:3].astype(np.int64)) ** 2).sum(1)
+        assert np.array_equal(dists[:, 0].astype(np.int64), want)
+    ids = rng.randint(0, n, size=50).astype(np.uint64)
+    kept, sc = eng.score_ids(queries[0], ids)
+    okept, osc = oracle.filter_by_score(base, queries[0], ids, float("inf"), oracle.METRIC_L2_I16_REFCOMPAT)
+    assert np.array_equal(kept, okept) and np.array_equal(sc, osc)
+    eng.close()
+
+
 def test_quantizer_builds_on_device(oracle):
     """quantizer_simple<uint8_t> (cast) and quantizer_ranged_q8 (affine int8) vs the oracle."""
     import ctypes as C

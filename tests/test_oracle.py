@@ -161,6 +161,19 @@ def test_int_kernels(oracle):
     assert oracle.int_kernel("oracle_l2_i16_refcompat", a16, b16) == 64 * (40000 - 65536)
 
 
+def test_int16_metric_in_brute_force(oracle):
+    """the int16 kernel (a-5b) is reachable through brute force / filter_by_score like the others"""
+    rng = np.random.RandomState(16)
+    base = rng.randint(-300, 300, size=(500, 64)).astype(np.int16)
+    q = rng.randint(-300, 300, size=(3, 64)).astype(np.int16)
+    ids, d = oracle.brute_force(base, q, 5, oracle.METRIC_L2_I16_REFCOMPAT)
+    for qi in range(3):
+        sc = np.array([oracle.int_kernel("oracle_l2_i16_refcompat", q[qi], base[r]) for r in range(500)])
+        order = np.lexsort((np.arange(500), sc.astype(np.float32)))[:5]
+        assert np.array_equal(ids[qi], order.astype(np.uint64))
+        assert np.array_equal(d[qi], sc[order].astype(np.float32))
+
+
 def test_u8_compressed(oracle):
     rng = np.random.RandomState(5)
     for d in (64, 128):
