@@ -1088,6 +1088,8 @@ restart_direct:
 						const uint32_t slots = kF16WgPerCu * (uint32_t)cus;
 						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
 						double best = 1e300;
+						double best8 = 1e300;
+						uint32_t g8 = 0;
 						for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
 							const uint32_t steps = (fp.n_tiles_sel + g - 1) / g;
 							const uint64_t blocks = (uint64_t)g * fp.n_qtiles;
@@ -1097,6 +1099,16 @@ restart_direct:
 								best = cost;
 								fchunks = g;
 							}
+							// a multiple of 8 whose rounding leaves exactly g chunks: XCD-aware placement
+							if (g % 8 == 0 && cost < best8 * 0.999 &&
+							    (fp.n_tiles_sel + steps - 1) / steps == g) {
+								best8 = cost;
+								g8 = g;
+							}
+						}
+						if (g8 && best8 <= best * 1.03 && !(h->opt_debug & 1024)) {
+							fchunks = g8;
+							fp.xcd_map = 1;
 						}
 					}
 					fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;

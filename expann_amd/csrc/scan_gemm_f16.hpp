@@ -138,6 +138,10 @@ struct GemmF16Params {
 	// (row mod 32) of g = q16.b16 - bn'  (larger g = nearer row); theta, cand* unused
 	float* sample_out;
 	uint32_t n_chunks;
+	// blocks b and b+8 share an XCD (observed dispatch order): with xcd_map the 8 row chunks
+	// {x, x+8, ...} and all their query tiles go to XCD x, so a tile is fetched into ONE L2
+	// instead of eight.  Needs the chunk count to be a multiple of 8.
+	uint32_t xcd_map;
 };
 
 __device__ inline float max3f(float a, float b, float c) {
@@ -187,8 +191,13 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int h = lane >> 5, r31 = lane & 31;
-	const uint32_t qtile = blockIdx.x % p.n_qtiles;
-	const uint32_t chunk = blockIdx.x / p.n_qtiles;
+	uint32_t qtile = blockIdx.x % p.n_qtiles;
+	uint32_t chunk = blockIdx.x / p.n_qtiles;
+	if (p.xcd_map) {
+		const uint32_t j = blockIdx.x >> 3;
+		qtile = j % p.n_qtiles;
+		chunk = (blockIdx.x & 7) + 8 * (j / p.n_qtiles);
+	}
 	const uint32_t wg_q0 = qtile * kF16TQ;
 	const uint32_t q0 = wg_q0 + wave * 64;  // this wave's 64 queries
 

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2_trace" -- python3 $B --steps 5 --warmup 1 > "$OUT/c2_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2_trace" -- python3 $B --steps 20 --warmup 3 > "$OUT/c2_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/m1_trace" -- python3 $B --steps 50 --warmup 2 --m 1 > "$OUT/m1_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/c2_fetch" -- python3 $B --steps 2 --warmup 1 > "$OUT/c2_fetch.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/m1_fetch" -- python3 $B --steps 5 --warmup 1 --m 1 > "$OUT/m1_fetch.log" 2>&1
