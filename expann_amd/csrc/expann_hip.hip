@@ -708,6 +708,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			const uint32_t slots = wg_slots;
 			const uint32_t gmax = std::max<uint32_t>(1, nt / 8);
 			double best = 1e300;
+			double best8 = 1e300;
+			uint32_t g8 = 0;
 			for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
 				const uint32_t steps = (nt + g - 1) / g;
 				const uint64_t rounds = ((uint64_t)g * nqt + slots - 1) / slots;
@@ -716,6 +718,14 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 					best = cost;
 					fchunks = g;
 				}
+				if (g % 8 == 0 && cost < best8 * 0.999 && (nt + steps - 1) / steps == g) {
+					best8 = cost;
+					g8 = g;
+				}
+			}
+			if (g8 && best8 <= best * 1.03 && !(h->opt_debug & 1024)) {
+				fchunks = g8;
+				fp.xcd_map = 1;
 			}
 		}
 		fp.tiles_per_block = (nt + fchunks - 1) / fchunks;

@@ -43,6 +43,7 @@ struct GemmI8qParams {
 	uint32_t cap;
 	int* sample_out;         // SAMPLE: [(q * n_chunks + chunk) * 32 + class] max g
 	uint32_t n_chunks;
+	uint32_t xcd_map;        // XCD-aware block placement, as GemmF16Params::xcd_map
 };
 
 // bp[i] = bias[i] >> 1 for i < n, kI8qPadBp for n <= i < n_pad (bias == nullptr: zeros)
@@ -107,8 +108,13 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int h = lane >> 5, r31 = lane & 31;
-	const uint32_t qtile = blockIdx.x % p.n_qtiles;
-	const uint32_t chunk = blockIdx.x / p.n_qtiles;
+	uint32_t qtile = blockIdx.x % p.n_qtiles;
+	uint32_t chunk = blockIdx.x / p.n_qtiles;
+	if (p.xcd_map) {
+		const uint32_t j = blockIdx.x >> 3;
+		qtile = j % p.n_qtiles;
+		chunk = (blockIdx.x & 7) + 8 * (j / p.n_qtiles);
+	}
 	const uint32_t wg_q0 = qtile * WGQ;
 	const uint32_t q0 = wg_q0 + wave * 32 * TQW;
 
