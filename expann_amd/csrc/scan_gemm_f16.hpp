@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)kF16WaveQueue ? wfill : (uint32_t)kF16WaveQueue;
-		constexpr int R = 4;
+		constexpr int R = 8;
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
 			uint32_t qi[R], slot[R];

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 	};
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		constexpr int R = 4;
+		constexpr int R = 8;
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
 			uint32_t qi[R], slot[R], row[R];
