@@ -514,12 +514,12 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 // one wave per query for lists of <= 512 keys, then (when the buffers allow longer lists) for
 // <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
 void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st) {
-	const dim3 grid((uint32_t)((m + kBlock / 64 - 1) / (kBlock / 64)));
 	sel.wave_done = 0;
-	hipLaunchKernelGGL(select_wave_kernel<8>, grid, dim3(kBlock), 0, st, sel, (uint32_t)m);
+	hipLaunchKernelGGL((select_wave_kernel<8, 4>), dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, sel,
+	                   (uint32_t)m);
 	sel.wave_done = 512;
 	if (cap > 512) {
-		hipLaunchKernelGGL(select_wave_kernel<32>, grid, dim3(kBlock), 0, st, sel, (uint32_t)m);
+		hipLaunchKernelGGL((select_wave_kernel<32, 1>), dim3((uint32_t)m), dim3(64), 0, st, sel, (uint32_t)m);
 		sel.wave_done = 2048;
 	}
 }

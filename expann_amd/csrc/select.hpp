@@ -201,8 +201,9 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
 // memory round trips whatever the arithmetic, so the win is 4x the queries in flight and no
 // workgroup barriers.  Longer lists are left to select_topk_kernel (which skips the queries
 // done here when p.wave_done is set).
-// the k smallest of the n_s <= 64*NE keys in list[], ascending, to the outputs (+ the next tau):
-// k rounds of wave-min extraction, lane 0 writes
+// the k smallest of the n_s <= 64*NE keys in list[], ascending, to the outputs (+ the next tau).
+// Small k: k rounds of wave-min extraction, lane 0 writes.  Larger k: every lane ranks its keys
+// by counting (all n_s keys stream past as LDS broadcasts) and writes them to their rank.
 template <int NE>
 __device__ inline void wave_emit_sorted(const SelectParams& p, const uint64_t* list, uint32_t n_s,
                                         uint32_t qi, int lane) {
@@ -210,6 +211,44 @@ __device__ inline void wave_emit_sorted(const SelectParams& p, const uint64_t* l
 #pragma unroll
 	for (int j = 0; j < NE; ++j)
 		e[j] = lane + 64 * j < (int)n_s ? list[lane + 64 * j] : kSentinelKey;
+	if (p.k > 16) {
+		uint32_t r[NE];
+#pragma unroll
+		for (int j = 0; j < NE; ++j)
+			r[j] = 0;
+		for (uint32_t i = 0; i < n_s; ++i) {
+			const uint64_t x = list[i];
+#pragma unroll
+			for (int j = 0; j < NE; ++j)
+				r[j] += x < e[j] ? 1u : 0u;
+		}
+#pragma unroll
+		for (int j = 0; j < NE; ++j) {
+			if (e[j] == kSentinelKey || r[j] >= p.k)
+				continue;  // (keys are distinct: ranks are a permutation)
+			if (p.out_ids)
+				p.out_ids[(size_t)qi * p.k + r[j]] = (uint64_t)key_idx(e[j]) + p.id_offset;
+			if (p.out_dists)
+				p.out_dists[(size_t)qi * p.k + r[j]] = key_score(e[j]);
+			if (r[j] == p.k - 1 && p.tau_out) {
+				p.tau_out[qi] = key_score(e[j]);
+				if (p.tau_row_out)
+					p.tau_row_out[qi] = key_idx(e[j]);
+			}
+		}
+		for (uint32_t i = n_s + lane; i < p.k; i += 64) {  // fewer than k keys: padding
+			if (p.out_ids)
+				p.out_ids[(size_t)qi * p.k + i] = ~0ull;
+			if (p.out_dists)
+				p.out_dists[(size_t)qi * p.k + i] = __builtin_inff();
+		}
+		if (lane == 0 && n_s < p.k && p.tau_out) {
+			p.tau_out[qi] = p.tau_prev ? p.tau_prev[qi] : __builtin_inff();
+			if (p.tau_row_out)
+				p.tau_row_out[qi] = p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu;
+		}
+		return;
+	}
 	for (uint32_t r = 0; r < p.k; ++r) {
 		uint64_t mn = e[0];
 #pragma unroll
@@ -269,13 +308,14 @@ template <int PER> __device__ inline uint32_t wave_kth_largest_u32(const uint32_
 	return lo;
 }
 
-template <int PER>  // lists of (64 * PER / 4, 64 * PER] keys (PER = 8: of at most 512)
-__global__ __launch_bounds__(kBlock) void select_wave_kernel(SelectParams p, uint32_t m) {
+// lists of at most 64 * PER keys; WAVES queries per workgroup (PER = 32: one, its list is 16 KB)
+template <int PER, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void select_wave_kernel(SelectParams p, uint32_t m) {
 	constexpr uint32_t kSelectWaveMax = 64 * PER;
-	__shared__ uint64_t lists[kBlock / 64][kSelectWaveMax];
+	__shared__ uint64_t lists[WAVES][kSelectWaveMax];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t qi = blockIdx.x * (kBlock / 64) + wave;
+	const uint32_t qi = blockIdx.x * WAVES + wave;
 	if (qi >= m)
 		return;
 	const uint32_t c = p.cand_cnt[qi];
