@@ -1290,7 +1290,9 @@ restart_direct:
 			if (last && sel.cand_cnt && h->profiling)  // statistics: candidates of the full scan
 				hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
 				                   h->d_total);
-			if (sel.rerank_base && sel.cand_cnt && !(h->opt_debug & 512)) {
+			if (m <= 64) {
+				sel.wave0_short = 1;  // latency mode: one launch, wave 0 orders the short lists
+			} else if (sel.rerank_base && sel.cand_cnt && !(h->opt_debug & 512)) {
 				// short lists (the usual case after a GEMM-form scan): one wave per query
 				launch_select_wave(sel, m, cap, st);
 			}

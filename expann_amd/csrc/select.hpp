@@ -36,6 +36,7 @@ struct SelectParams {
 	const float* bn_max;      // [1] max over rows of ||b||^2 (1-eps)
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
 	uint32_t wave_done;       // select_wave_kernel already served the lists of <= wave_done keys
+	uint32_t wave0_short;     // select_topk_kernel: lists of <= 2048 keys go through wave 0's wave path
 };
 
 // statistics: *out = sum of counts (one workgroup; one same-address atomic per query in the
@@ -308,20 +309,10 @@ template <int PER> __device__ inline uint32_t wave_kth_largest_u32(const uint32_
 	return lo;
 }
 
-// lists of at most 64 * PER keys; WAVES queries per workgroup (PER = 32: one, its list is 16 KB)
-template <int PER, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void select_wave_kernel(SelectParams p, uint32_t m) {
-	constexpr uint32_t kSelectWaveMax = 64 * PER;
-	__shared__ uint64_t lists[WAVES][kSelectWaveMax];
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t qi = blockIdx.x * WAVES + wave;
-	if (qi >= m)
-		return;
-	const uint32_t c = p.cand_cnt[qi];
-	if (c > kSelectWaveMax || c > p.cap || (c <= p.wave_done && p.wave_done != 0))
-		return;  // longer lists: the next size up; shorter ones: already served
-	uint64_t* list = lists[wave];
+// one wave orders the list of query qi (c <= 64 * PER keys); list = 64 * PER keys of LDS
+template <int PER>
+__device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint32_t c, uint64_t* list,
+                                        int lane) {
 	const uint64_t* src = p.cand + (size_t)qi * p.cap;
 	uint64_t kk[PER];
 #pragma unroll
@@ -411,6 +402,22 @@ __global__ __launch_bounds__(64 * WAVES) void select_wave_kernel(SelectParams p,
 		wave_emit_sorted<PER>(p, list, n_s, qi, lane);
 }
 
+// lists of at most 64 * PER keys; WAVES queries per workgroup (PER = 32: one, its list is 16 KB)
+template <int PER, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void select_wave_kernel(SelectParams p, uint32_t m) {
+	constexpr uint32_t kSelectWaveMax = 64 * PER;
+	__shared__ uint64_t lists[WAVES][kSelectWaveMax];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t qi = blockIdx.x * WAVES + wave;
+	if (qi >= m)
+		return;
+	const uint32_t c = p.cand_cnt ? p.cand_cnt[qi] : p.fixed_count;
+	if (c > kSelectWaveMax || c > p.cap || (c <= p.wave_done && p.wave_done != 0))
+		return;  // longer lists: the next size up; shorter ones: already served
+	select_wave_body<PER>(p, qi, c, lists[wave], lane);
+}
+
 // One workgroup per query: bitonic sort of the (power-of-two padded) key list in LDS.
 __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -420,6 +427,17 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	uint32_t c = p.cand_cnt ? p.cand_cnt[qi] : p.fixed_count;
 	if (p.wave_done && c <= p.wave_done)
 		return;  // (uniform per workgroup)
+	if (p.wave0_short && c <= 2048 && c <= p.cap && 8 * (size_t)p.cap >= 16384) {
+		// few queries in the launch: no separate wave kernels; wave 0 of this workgroup takes the
+		// short list, the other waves leave
+		if (tid < 64) {
+			if (c <= 512)
+				select_wave_body<8>(p, qi, c, keys, (int)tid);
+			else
+				select_wave_body<32>(p, qi, c, keys, (int)tid);
+		}
+		return;
+	}
 	if (c > p.cap) {
 		if (tid == 0)
 			atomicAdd(p.overflow, 1u);
