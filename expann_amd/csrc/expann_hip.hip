@@ -54,6 +54,7 @@ constexpr int kEventPairs = 64;
 struct Level {
 	uint32_t n_groups_sel;
 	uint32_t group_stride;
+	uint32_t classmin_blocks = 0;  // > 0: level 0 keeps class minima (scan_f32.hpp), this many workgroups
 };
 
 }  // namespace
@@ -927,8 +928,25 @@ restart_direct:
 		int rc = ensure_workspace(h, m, cap);
 		if (rc != EXPANN_OK)
 			return rc;
-		const std::vector<Level> levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
+		std::vector<Level> levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
 		const uint32_t n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
+		if (!gv && !gvi && levels.size() >= 3 && h->opt_sample_pass) {
+			// direct path: ONE sampled level of class minima (1/16 of the rows) instead of the
+			// first two levels of the ladder -- a launch chain shorter by a scan, a select and a
+			// memset, and ~10 k instead of ~32 k candidates in the full scan
+			const uint32_t n_groups = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
+			const uint32_t sel = n_groups / 16;
+			uint32_t blocks = std::min<uint32_t>({128u, cap / 16, sel / 8});
+			if (blocks * 16 >= 8 * k && blocks >= 16) {
+				Level l0;
+				l0.n_groups_sel = sel;
+				l0.group_stride = 16;
+				l0.classmin_blocks = blocks;
+				levels.clear();
+				levels.push_back(l0);
+				levels.push_back(Level{n_groups, 1, 0});
+			}
+		}
 		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
 		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
 		// fp16 form on a large index: ONE sampled pass (1/16 of the rows, class maxima per query,
@@ -1013,6 +1031,10 @@ restart_direct:
 			uint32_t target_chunks = (uint32_t)std::max<long>(1, (16L * cus + n_qtiles - 1) / n_qtiles);
 			uint32_t max_chunks = std::max<uint32_t>(1, L.n_groups_sel / 8);
 			uint32_t n_chunks = std::min(target_chunks, max_chunks);
+			if (first && L.classmin_blocks) {
+				n_chunks = L.classmin_blocks;
+				sp.classmin = 1;
+			}
 			sp.groups_per_block = (L.n_groups_sel + n_chunks - 1) / n_chunks;
 			n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
 			if (!first && !theta_ready)
@@ -1265,7 +1287,7 @@ restart_direct:
 			SelectParams sel{};
 			sel.cand = h->d_cand;
 			sel.cand_cnt = first ? nullptr : h->d_cnt;
-			sel.fixed_count = (h->opt_debug & 256) ? 12345 : L.n_groups_sel * kRowsPerGroup;
+			sel.fixed_count = (first && L.classmin_blocks) ? n_chunks * 16 : L.n_groups_sel * kRowsPerGroup;
 			sel.cap = cap;
 			sel.k = (uint32_t)k;
 			sel.id_offset = h->id_offset;

@@ -35,6 +35,11 @@ struct ScanParams {
 	uint32_t* cand_cnt;       // [m]
 	uint64_t* cand;           // [m][cap] keys (common.hpp: make_key)
 	uint32_t cap;
+	// level 0 only (tau == nullptr): instead of every key of the sample, keep the SMALLEST key of
+	// each class = (workgroup, wave, 16-lane row group), at slot workgroup*16 + wave*4 + group.
+	// The k smallest class minima are k different rows, so their k-th is a valid (score, row)
+	// threshold -- from a 16x larger sample than a keep-all level can afford, in one launch.
+	uint32_t classmin;
 };
 
 template <int D, int TQ, bool IP>
@@ -91,6 +96,10 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 		for (int t = 0; t < DPL; t += 2)
 			r[t / 2] = f32x2{src[16 * t], src[16 * t + 16]};
 	};
+	uint64_t best[TQ];  // class minima (classmin level)
+#pragma unroll
+	for (int j = 0; j < TQ; ++j)
+		best[j] = kSentinelKey;
 	auto process = [&](const f32x2 (&r)[DPL / 2], uint32_t g) {
 		const uint32_t row = row_of(g);
 		const bool rvalid = row < p.n_rows;
@@ -130,7 +139,13 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 			s[j] = IP ? -red : red;
 			any |= __builtin_amdgcn_ballot_w64(s[j] <= tau[j]);
 		}
-		if (level0) {
+		if (level0 && p.classmin) {
+#pragma unroll
+			for (int j = 0; j < TQ; ++j) {
+				const uint64_t key = rvalid ? make_key(s[j], row) : kSentinelKey;
+				best[j] = key < best[j] ? key : best[j];
+			}
+		} else if (level0) {
 			// keep every row of the sample at its sample position (no atomics)
 			const uint32_t slot = g * kRowsPerGroup + wave * kRowsPerWaveStep + rg;
 			if (l == 0 && slot < p.cap) {
@@ -173,6 +188,15 @@ __global__ __launch_bounds__(kBlock) void scan_filter_f32_kernel(ScanParams p) {
 	}
 	if (g < g1)
 		process(ra, g);
+	if (level0 && p.classmin) {
+		const uint32_t slot = chunk * 16 + wave * 4 + rg;
+		if (l == 0 && slot < p.cap) {
+#pragma unroll
+			for (int j = 0; j < TQ; ++j)
+				if (q0 + j < p.m)
+					p.cand[(size_t)(q0 + j) * p.cap + slot] = best[j];
+		}
+	}
 }
 
 }  // namespace expann

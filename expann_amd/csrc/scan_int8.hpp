@@ -119,6 +119,10 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 		for (int w = 0; w < NW; ++w)
 			r[w] = src[w];
 	};
+	uint64_t best[TQ];  // class minima (classmin level, scan_f32.hpp)
+#pragma unroll
+	for (int j = 0; j < TQ; ++j)
+		best[j] = kSentinelKey;
 	auto process = [&](const int (&r)[NW], uint32_t g) {
 		const uint32_t row = row_of(g);
 		const bool rvalid = row < p.n_rows;
@@ -137,7 +141,13 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 			s[j] = (float)tot;
 			any |= __builtin_amdgcn_ballot_w64(s[j] <= tau[j]);
 		}
-		if (level0) {
+		if (level0 && p.classmin) {
+#pragma unroll
+			for (int j = 0; j < TQ; ++j) {
+				const uint64_t key = rvalid ? make_key(s[j], row) : kSentinelKey;
+				best[j] = key < best[j] ? key : best[j];
+			}
+		} else if (level0) {
 			const uint32_t slot = g * kRowsPerGroup + wave * kRowsPerWaveStep + rg;
 			if (l == 0 && slot < p.cap) {
 #pragma unroll
@@ -175,6 +185,15 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 	}
 	if (g < g1)
 		process(ra, g);
+	if (level0 && p.classmin) {
+		const uint32_t slot = chunk * 16 + wave * 4 + rg;
+		if (l == 0 && slot < p.cap) {
+#pragma unroll
+			for (int j = 0; j < TQ; ++j)
+				if (q0 + j < p.m)
+					p.cand[(size_t)(q0 + j) * p.cap + slot] = best[j];
+		}
+	}
 }
 
 // fp32 query -> uint8 (trunc), as `uint32_t(q[i])` in src/antitopo_engine.h:726-737; values
