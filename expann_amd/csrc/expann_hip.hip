@@ -433,9 +433,12 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
 		return nullptr;
-	// measured crossover at N = 1M, d = 128 (bf16x3 form): m = 16: 0.34 vs 0.37 ms per step,
-	// m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins
-	if (h->opt_scan_kernel == 0 && (m < 24 || h->n < 4096))
+	// measured crossovers at N = 1M, d = 128.  bf16x3 / fp32 forms: m = 16: 0.34 vs 0.37 ms per
+	// step, m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins.  fp16
+	// form (half the bytes per row, one sampled pass): 0.175 vs 0.175 ms at m = 4, 0.173 vs 0.199
+	// at m = 8, 0.185 vs 0.31 at m = 16 -- from 5 queries on it wins.
+	const bool f16_dims = (h->dim == 64 || h->dim == 128) && h->f16_scale >= 0.0f;
+	if (h->opt_scan_kernel == 0 && (m < (f16_dims ? 5u : 24u) || h->n < 4096))
 		return nullptr;
 	for (const auto& v : kGemmF32)
 		if (v.d == h->dim)
@@ -875,6 +878,8 @@ restart_direct:
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64 or 128 only");
 	if (gvf)
 		gvb = nullptr;
+	else if (h->opt_scan_kernel == 0 && m < 24)
+		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on
 	if (gv && !gvf) {
 		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
 		if (rc != EXPANN_OK)
