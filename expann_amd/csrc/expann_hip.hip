@@ -335,8 +335,9 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		h->cand_elems = need;
 	}
 	if (!h->d_overflow) {
-		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4));
-		HIP_TRY(h, hipMalloc(&h->d_total, sizeof(unsigned long long) * 2));
+		// flags [4 x u32] and statistics [2 x u64] share one allocation: one memset, one read-back
+		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
+		h->d_total = reinterpret_cast<unsigned long long*>(h->d_overflow + 4);
 		HIP_TRY(h, hipHostMalloc((void**)&h->h_flags, sizeof(uint32_t) * 8, 0));
 	}
 	return EXPANN_OK;
@@ -368,17 +369,20 @@ const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16x3_kernel<64>, "scan_gem
 
 using GemmF16Fn = void (*)(GemmF16Params);
 using SqnormFn = void (*)(const float*, uint32_t, float*);
+using F16PrepFn = void (*)(const float*, uint32_t, float, _Float16*, float*, uint32_t*);
 struct GemmF16Variant {
 	int d;
 	GemmF16Fn scan;
 	GemmF16Fn sample;
 	SqnormFn sqnorm;
+	F16PrepFn prep;
 	const char* name;
 };
 const GemmF16Variant kGemmF16[] = {
-    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>, "scan_gemm_f16<64, false>"},
+    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>,
+     f16_query_prep_kernel<64>, "scan_gemm_f16<64, false>"},
     {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
-     "scan_gemm_f16<128, false>"}};
+     f16_query_prep_kernel<128>, "scan_gemm_f16<128, false>"}};
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
@@ -770,8 +774,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock), sizeof(uint64_t) * cap + 16,
 		                   st, sel);
 		HIP_TRY(h, hipGetLastError());
-		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(h, hipMemcpyAsync(h->h_flags + 4, h->d_total, sizeof(unsigned long long),
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
 		                          hipMemcpyDeviceToHost, st));
 		HIP_TRY(h, hipStreamSynchronize(st));
 		unsigned long long tot;
@@ -847,6 +850,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		if (rq != kRetryGeneric)
 			return rq;
 	}
+	bool flags_clean = false;   // the fp16 prelude has just zeroed the flag block
 	bool force_direct = false;  // set when a GEMM-form filter overflowed: massive near-ties
 	bool no_f16 = false;        // set when the queries do not fit the fp16 range of this index
 restart_direct:
@@ -904,14 +908,13 @@ restart_direct:
 			HIP_TRY(h, hipMalloc(&h->d_q_split, nv * 4));
 			h->q_split_bytes = nv * 4;
 		}
-		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end)
-		HIP_TRY(h, hipMemsetAsync(h->d_overflow + 2, 0, sizeof(uint32_t), st));
-		hipLaunchKernelGGL(convert_f16_kernel,
-		                   dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 1024)),
-		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->f16_scale,
-		                   (_Float16*)h->d_q_split, h->d_overflow + 2);
-		hipLaunchKernelGGL(gvf->sqnorm, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
-		                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m, h->d_qnrm);
+		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end):
+		// one memset of the flag block, one kernel
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, 32, st));
+		flags_clean = true;
+		hipLaunchKernelGGL(gvf->prep, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)), dim3(kBlock),
+		                   0, st, (const float*)d_queries, (uint32_t)m, h->f16_scale, (_Float16*)h->d_q_split,
+		                   h->d_qnrm, h->d_overflow + 2);
 		HIP_TRY(h, hipGetLastError());
 	}
 	if (gvb) {  // queries -> bf16 hi/lo planes
@@ -952,8 +955,11 @@ restart_direct:
 				levels.push_back(Level{n_groups, 1, 0});
 			}
 		}
-		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
-		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
+		if (!flags_clean) {  // overflow count and statistics (words 1, 2: uint8 / fp16 range flags, kept)
+			HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
+			HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
+		}
+		flags_clean = false;
 		// fp16 form on a large index: ONE sampled pass (1/16 of the rows, class maxima per query,
 		// scan_gemm_f16.hpp) gives the threshold of the full scan -- no direct level-0 scan, no
 		// intermediate candidate lists and selects
@@ -1327,10 +1333,8 @@ restart_direct:
 			                   sizeof(uint64_t) * cap + 16, st, sel);
 			HIP_TRY(h, hipGetLastError());
 		}
-		// overflow check (the only host sync of a search)
-		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4,
-		                          hipMemcpyDeviceToHost, st));
-		HIP_TRY(h, hipMemcpyAsync(h->h_flags + 4, h->d_total, sizeof(unsigned long long),
+		// overflow check (the only host sync of a search); flags and statistics are contiguous
+		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
 		                          hipMemcpyDeviceToHost, st));
 		HIP_TRY(h, hipStreamSynchronize(st));
 		unsigned long long tot;
@@ -1548,7 +1552,6 @@ void expann_destroy(expann_index* h) {
 	if (h->d_bias_i) hipFree(h->d_bias_i);
 	if (h->d_qself) hipFree(h->d_qself);
 	if (h->d_theta) hipFree(h->d_theta);
-	if (h->d_total) hipFree(h->d_total);
 	if (h->h_flags) hipHostFree(h->h_flags);
 	if (h->d_q) hipFree(h->d_q);
 	if (h->d_q8) hipFree(h->d_q8);

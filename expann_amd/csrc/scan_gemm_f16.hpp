@@ -102,6 +102,47 @@ __global__ __launch_bounds__(kBlock) void sqnorm_kernel(const float* x, uint32_t
 	if (i < n && l == 0)
 		out[i] = acc;
 }
+// Query side of a search in ONE launch: scaled fp16 copy, ||q||^2 in the reference lane order and
+// the bit pattern of max |q| (range check).  16 lanes per query row, as sqnorm_kernel.
+template <int D>
+__global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, uint32_t m, float scale,
+                                                                _Float16* q16, float* qnrm,
+                                                                uint32_t* maxabs_bits) {
+	__shared__ uint32_t red[kBlock / 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int l = lane & 15, rg = lane >> 4;
+	const uint32_t i = blockIdx.x * kRowsPerGroup + wave * kRowsPerWaveStep + rg;
+	const uint32_t ii = i < m ? i : m - 1;
+	const float* src = q + (size_t)ii * D + l;
+	float acc = 0.0f;
+	uint32_t b = 0;
+#pragma unroll
+	for (int t = 0; t < D / 16; ++t) {
+		const float v = src[16 * t];
+		acc = __builtin_fmaf(v, v, acc);
+		const uint32_t vb = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
+		b = vb > b ? vb : b;
+		if (i < m)
+			q16[(size_t)i * D + l + 16 * t] = (_Float16)(v * scale);
+	}
+	acc = reduce16_ref_order(acc);
+	if (i < m && l == 0)
+		qnrm[i] = acc;
+	for (int off = 32; off > 0; off >>= 1) {
+		const uint32_t o = (uint32_t)__shfl_xor((int)b, off);
+		b = o > b ? o : b;
+	}
+	if (lane == 0)
+		red[wave] = b;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < kBlock / 64; ++w)
+			b = red[w] > b ? red[w] : b;
+		if (b != 0)
+			atomicMax(maxabs_bits, b);
+	}
+}
+
 // rows:    out = (nrm*(1-eps) - abs*sqrt(nrm)) * mul                (tau == nullptr)
 // queries: out = (tau - (nrm*(1-eps) - abs*sqrt(nrm))) * mul
 // mul = s^2/2, a power of two: the scaling is exact
@@ -541,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
 	uint64_t kth = 0;
-	if (p.k > 24) {  // bisection on the value: 32 steps whatever k
+	if (p.k > 24 || PER >= 16) {  // bisection on the value: 32 steps whatever k and list length
 		uint32_t ord[PER];
 #pragma unroll
 		for (int j = 0; j < PER; ++j)
