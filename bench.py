@@ -382,6 +382,12 @@ def main():
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                         "mfma_dtype": "fp16 (filter only; results exact after fp32 re-rank)",
                         "algorithmic_vs_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 3)}
+            if passes <= 2:
+                # a handful of queries: one or two passes over the fp16 rows, the HBM read is the bound
+                gbs = passes * n_local * a.d * 2 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+                roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "note": "small batch: bytes = query tiles x N x d x 2 (the fp16 rows the filter reads)"}
         elif prof["scan_kernel"].startswith("scan_gemm_bf16x3"):
             # fp32 products evaluated exactly enough on the bf16 cores as 3 bf16 MFMA products
             # (hi*hi + hi*lo + lo*hi): executed flops = 3 x the algorithmic 2*N*d*m
