@@ -1325,7 +1325,7 @@ restart_direct:
 				                   h->d_total);
 			if (m <= 64) {
 				sel.wave0_short = 1;  // latency mode: one launch, wave 0 orders the short lists
-			} else if (sel.rerank_base && sel.cand_cnt && !(h->opt_debug & 512)) {
+			} else if (sel.rerank_base && sel.cand_cnt) {
 				// short lists (the usual case after a GEMM-form scan): one wave per query
 				launch_select_wave(sel, m, cap, st);
 			}

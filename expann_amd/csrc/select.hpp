@@ -59,125 +59,6 @@ __global__ __launch_bounds__(1024) void sum_u32_kernel(const uint32_t* in, uint3
 	}
 }
 
-// Short candidate lists of the GEMM forms (<= kSelectSmallMax row numbers with approximate
-// scores): no sort.  Ranks come from counting (every thread compares its keys with all others
-// through LDS broadcasts), the survivors of the pruning cut are re-scored exactly in one batch
-// of independent row loads, and the exact keys are ranked by counting again.  Four barriers.
-constexpr uint32_t kSelectSmallMax = 512;
-
-__device__ inline void select_small(const SelectParams& p, uint64_t* keys, uint32_t c, uint32_t qi) {
-	const uint32_t tid = threadIdx.x;
-	// LDS: keys[512] | exact[512] | counters
-	uint64_t* exact = keys + kSelectSmallMax;
-	uint32_t* s_n = reinterpret_cast<uint32_t*>(exact + kSelectSmallMax);
-	float* s_cut = reinterpret_cast<float*>(s_n + 1);
-	const uint64_t* src = p.cand + (size_t)qi * p.cap;
-	const uint64_t k0 = tid < c ? src[tid] : kSentinelKey;
-	const uint64_t k1 = tid + kBlock < c ? src[tid + kBlock] : kSentinelKey;
-	keys[tid] = k0;
-	keys[tid + kBlock] = k1;
-	if (tid == 0) {
-		*s_n = 0;
-		*s_cut = __builtin_inff();
-	}
-	const uint32_t l = tid & 15, grp = tid >> 4;  // 16 lanes per candidate row
-	const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
-	const bool prune = p.prune_eps > 0.0f && !p.metric_ip && c > p.k;
-	__syncthreads();
-	if (prune) {
-		uint32_t r0 = 0, r1 = 0;
-		for (uint32_t j = 0; j < c; ++j) {
-			const uint64_t x = keys[j];
-			r0 += x < k0 ? 1u : 0u;
-			r1 += x < k1 ? 1u : 0u;
-		}
-		float qn = 0.0f;
-		for (uint32_t t = 0; t < p.dim / 16; ++t)
-			qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
-		qn = reduce16_ref_order(qn);
-		const float bmax = p.bn_max[0];
-		const float margin = p.prune_eps * (qn + 1.5f * bmax) +
-		                     p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
-		if (r0 == p.k - 1 && tid < c)
-			*s_cut = key_score(k0) + margin;
-		if (r1 == p.k - 1 && tid + kBlock < c)
-			*s_cut = key_score(k1) + margin;
-		__syncthreads();
-	}
-	{
-		const float cut = *s_cut;
-		if (tid < c && key_score(k0) <= cut)
-			exact[atomicAdd(s_n, 1u)] = k0;  // (the survivor list lives in exact[] until re-scored)
-		if (tid + kBlock < c && key_score(k1) <= cut)
-			exact[atomicAdd(s_n, 1u)] = k1;
-	}
-	__syncthreads();
-	const uint32_t n_s = *s_n;
-	// exact re-score (lane l owns dims l, l+16, ...; _mm512_reduce_add_ps tree): bit-identical to
-	// scan_filter_f32_kernel's scores (src/distance.h:136-147 / :181-190).  Four candidates per
-	// 16-lane group in flight.
-	for (uint32_t i0 = 0; i0 < n_s; i0 += 4 * (kBlock / 16)) {
-		float acc[4];
-		uint32_t row[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t i = i0 + u * (kBlock / 16) + grp;
-			row[u] = i < n_s ? key_idx(exact[i]) : key_idx(exact[0]);
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const float* r = p.rerank_base + (size_t)row[u] * p.dim + l;
-			float a = 0.0f;
-			for (uint32_t t = 0; t < p.dim / 16; ++t) {
-				if (p.metric_ip) {
-					a = __builtin_fmaf(q[16 * t], r[16 * t], a);
-				} else {
-					const float diff = q[16 * t] - r[16 * t];
-					a = __builtin_fmaf(diff, diff, a);
-				}
-			}
-			acc[u] = reduce16_ref_order(a);
-		}
-		__syncthreads();  // every survivor of this batch has been read
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t i = i0 + u * (kBlock / 16) + grp;
-			if (l == 0 && i < n_s)
-				keys[i] = make_key(p.metric_ip ? -acc[u] : acc[u], row[u]);
-		}
-	}
-	__syncthreads();
-	// rank the exact keys by counting; rank r goes to output slot r
-	for (uint32_t i = tid; i < n_s; i += kBlock) {
-		const uint64_t mine = keys[i];
-		uint32_t r = 0;
-		for (uint32_t j = 0; j < n_s; ++j)
-			r += keys[j] < mine ? 1u : 0u;
-		if (r < p.k) {
-			if (p.out_ids)
-				p.out_ids[(size_t)qi * p.k + r] = (uint64_t)key_idx(mine) + p.id_offset;
-			if (p.out_dists)
-				p.out_dists[(size_t)qi * p.k + r] = key_score(mine);
-		}
-		if (r == p.k - 1 && p.tau_out) {
-			p.tau_out[qi] = key_score(mine);
-			if (p.tau_row_out)
-				p.tau_row_out[qi] = key_idx(mine);
-		}
-	}
-	for (uint32_t i = n_s + tid; i < p.k; i += kBlock) {  // fewer than k candidates: padding
-		if (p.out_ids)
-			p.out_ids[(size_t)qi * p.k + i] = ~0ull;
-		if (p.out_dists)
-			p.out_dists[(size_t)qi * p.k + i] = __builtin_inff();
-	}
-	if (tid == 0 && n_s < p.k && p.tau_out) {
-		p.tau_out[qi] = p.tau_prev ? p.tau_prev[qi] : __builtin_inff();
-		if (p.tau_row_out)
-			p.tau_row_out[qi] = p.tau_row_prev ? p.tau_row_prev[qi] : 0xFFFFFFFFu;
-	}
-}
-
 // min over the 64 lanes (result in every lane)
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
 	// within rows of 16 by DPP rotations, then across the four rows
@@ -197,11 +78,14 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
 	return ((uint64_t)mhi << 32) | wave_min_u32(lo);
 }
 
-// The same job as select_small, one WAVE per query (lists of <= kSelectWaveMax candidates of a
-// GEMM-form scan; rerank_base == nullptr: the keys already carry their final scores): the chain count -> keys -> candidate rows -> output is three dependent
-// memory round trips whatever the arithmetic, so the win is 4x the queries in flight and no
-// workgroup barriers.  Longer lists are left to select_topk_kernel (which skips the queries
-// done here when p.wave_done is set).
+// ---- one WAVE per query -------------------------------------------------------------------
+// Lists of at most 2048 candidates (what the sampled thresholds leave) are ordered by a single
+// wave: the chain count -> keys -> candidate rows -> output is three dependent memory round
+// trips whatever the arithmetic, so the win over one 256-thread workgroup per query is 4x the
+// queries in flight and no workgroup barriers.  With rerank_base the keys carry approximate
+// scores of a GEMM-form scan (pruned, then re-scored exactly); without, final scores.  Longer
+// lists are left to select_topk_kernel (which skips the queries served here: p.wave_done).
+
 // the k smallest of the n_s <= 64*NE keys in list[], ascending, to the outputs (+ the next tau).
 // Small k: k rounds of wave-min extraction, lane 0 writes.  Larger k: every lane ranks its keys
 // by counting (all n_s keys stream past as LDS broadcasts) and writes them to their rank.
@@ -442,10 +326,6 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 		if (tid == 0)
 			atomicAdd(p.overflow, 1u);
 		c = p.cap;
-	}
-	if (p.rerank_base && c <= kSelectSmallMax && p.cap >= 2 * kSelectSmallMax + 2 && p.fixed_count != 12345) {
-		select_small(p, keys, c, qi);  // (uniform per workgroup)
-		return;
 	}
 	uint32_t n2 = 2;
 	while (n2 < c)
