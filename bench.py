@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--sample-ratio", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-run", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sift-like", action="store_true",
+                    help="f32 rows and queries hold integers 0..255 (SURVEY 8d's SIFT stand-in)")
     ap.add_argument("--clustered", type=int, default=0,
                     help="synthetic base = this many Gaussian clusters stored contiguously (robustness "
                          "probe; default 0 = iid rows)")
@@ -248,6 +250,9 @@ def main():
         base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
         g.manual_seed(4321)
         queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
+        if a.sift_like:
+            base = base.abs_().mul_(40).round_().clamp_(0, 255)
+            queries = queries.abs_().mul_(40).round_().clamp_(0, 255)
         if a.clustered and G == 1:
             # rows sorted by cluster: centres N(0, 1), members centre + 0.3 N(0, 1); queries near centres
             centres = torch.randn(a.clustered, a.d, device=dev, generator=g)

@@ -87,6 +87,15 @@ struct expann_index {
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
 	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
 	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
+	// fp32 index whose values are all integers in [0, 255] (SIFT): searches with integer queries
+	// go through an internal uint8 engine -- exact integer scores, equal to the fp32 ones bit for
+	// bit while d * 255^2 < 2^24 -- at the 8-bit kernels' speed
+	int u8_exact = 0;                // 0 not examined, 1 yes (shadow built), -1 no
+	expann_index* u8_shadow = nullptr;
+	void* d_base_u8 = nullptr;
+	bool strict_u8 = false;          // (on the shadow) non-8-bit / fractional queries: hand back, no error
+	double prof_extra_ms = 0;        // scan time absorbed from the shadow
+	long opt_u8_exact = 1;
 	void* d_base_i8q = nullptr;      // padded int8 copy of an 8-bit index (uint8 rows ^ 0x80) or alias of d_base
 	bool base_i8q_owned = false;
 	int* d_bp_i8q = nullptr;         // [n padded] floor(bias/2), scan_gemm_i8q.hpp
@@ -562,6 +571,7 @@ int i8q_lds_bytes(int d) {
 int i8q_threads(int d) { return d == 768 ? I8qGeom<768>::THREADS : I8qGeom<128>::THREADS; }
 int i8q_wg_per_cu(int d) { return d == 768 ? I8qGeom<768>::WG_PER_CU : I8qGeom<128>::WG_PER_CU; }
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
+constexpr int kStrictReject = -1001;  // internal (uint8 shadow): these queries are not 8-bit integers
 
 const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
 	if (h->dtype == EXPANN_DTYPE_F32 || !(h->opt_scan_kernel == 0 || h->opt_scan_kernel == 5))
@@ -780,6 +790,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		unsigned long long tot;
 		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
 		h->prof.candidates = tot;
+		if (h->strict_u8 && (h->h_flags[1] != 0 || h->h_flags[3] != 0))
+			return kStrictReject;
 		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
 			return h->fail(EXPANN_ERR_UNSUPPORTED,
 			               std::to_string(h->h_flags[1]) +
@@ -794,10 +806,111 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	}
 }
 
+int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
+                float* d_dists, hipStream_t st);
+}  // namespace
+extern "C" int expann_create(int dim, int dtype, int metric, int device, expann_index** out);
+extern "C" int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64_t id_offset);
+extern "C" int expann_set_profiling(expann_index* h, int enable);
+extern "C" void expann_destroy(expann_index* h);
+namespace {
+
+// Exact-uint8 shortcut of an fp32 index (fields of expann_index): examine the rows once; if all
+// are integers in [0, 255] keep a uint8 copy behind an internal uint8 engine.
+int build_u8_shadow(expann_index* h, hipStream_t st) {
+	const size_t nv = h->n * (size_t)h->dim;
+	DevBuf bad;
+	HIP_TRY(h, bad.alloc(sizeof(uint32_t)));
+	HIP_TRY(h, hipMemsetAsync(bad.p, 0, sizeof(uint32_t), st));
+	hipLaunchKernelGGL(count_non_u8_kernel, dim3(2048), dim3(kBlock), 0, st, (const float*)h->d_base, nv,
+	                   bad.as<uint32_t>());
+	uint32_t n_bad = 1;
+	HIP_TRY(h, hipMemcpyAsync(&n_bad, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(h, hipStreamSynchronize(st));
+	if (n_bad != 0) {
+		h->u8_exact = -1;
+		return EXPANN_OK;
+	}
+	HIP_TRY(h, hipMalloc(&h->d_base_u8, nv));
+	hipLaunchKernelGGL(cast_f32_u8_kernel, dim3(4096), dim3(kBlock), 0, st, (const float*)h->d_base, nv,
+	                   (uint8_t*)h->d_base_u8);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(st));
+	expann_index* sh = nullptr;
+	int rc = expann_create(h->dim, EXPANN_DTYPE_U8, EXPANN_METRIC_L2, h->device, &sh);
+	if (rc == EXPANN_OK)
+		rc = expann_set_base_device(sh, h->d_base_u8, h->n, h->id_offset);
+	if (rc == EXPANN_OK && h->profiling)
+		rc = expann_set_profiling(sh, 1);
+	if (rc != EXPANN_OK) {
+		if (sh)
+			expann_destroy(sh);
+		hipFree(h->d_base_u8);
+		h->d_base_u8 = nullptr;
+		h->u8_exact = -1;  // (not fatal: the fp32 paths serve the index)
+		return EXPANN_OK;
+	}
+	sh->strict_u8 = true;
+	h->u8_shadow = sh;
+	h->u8_exact = 1;
+	return EXPANN_OK;
+}
+void drop_u8_shadow(expann_index* h) {
+	if (h->u8_shadow)
+		expann_destroy(h->u8_shadow);
+	h->u8_shadow = nullptr;
+	if (h->d_base_u8)
+		hipFree(h->d_base_u8);
+	h->d_base_u8 = nullptr;
+	h->u8_exact = 0;
+}
+// the shadow's counters and scan time become the parent's
+int absorb_shadow_profile(expann_index* h) {
+	expann_index* sh = h->u8_shadow;
+	double ms = 0;
+	for (int i = 0; i < sh->ev_used; ++i) {
+		HIP_TRY(h, hipEventSynchronize(sh->ev[i][1]));
+		float t = 0;
+		HIP_TRY(h, hipEventElapsedTime(&t, sh->ev[i][0], sh->ev[i][1]));
+		ms += t;
+	}
+	sh->ev_used = 0;
+	h->prof_extra_ms += ms;
+	h->prof.scan_launches += sh->prof.scan_launches;
+	h->prof.scan_rows += sh->prof.scan_rows;
+	h->prof.scan_query_tiles += sh->prof.scan_query_tiles;
+	h->prof.retries += sh->prof.retries;
+	h->prof.query_tile = sh->prof.query_tile;
+	h->prof.levels = sh->prof.levels;
+	h->prof.candidates = sh->prof.candidates;
+	std::memcpy(h->prof.scan_kernel, sh->prof.scan_kernel, sizeof(h->prof.scan_kernel));
+	sh->prof = expann_profile{};
+	return EXPANN_OK;
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
 	const bool ip = (h->metric == EXPANN_METRIC_IP);
+	if (h->dtype == EXPANN_DTYPE_F32 && !ip && h->opt_scan_kernel == 0 && h->opt_u8_exact &&
+	    (h->dim == 128 || h->dim == 256) && m >= 96 && h->n >= 65536 && k <= 256 && h->u8_exact >= 0) {
+		// rows that are all integers in [0, 255] (SIFT): with integer queries the uint8 engine's
+		// exact integer scores ARE the fp32 scores (d * 255^2 < 2^24: every partial sum of the
+		// reference is an exactly represented integer), at the 8-bit kernels' speed
+		if (h->u8_exact == 0) {
+			const int rb = build_u8_shadow(h, st);
+			if (rb != EXPANN_OK)
+				return rb;
+		}
+		if (h->u8_exact == 1) {
+			const int rq = search_pass(h->u8_shadow, d_queries, m, k, d_ids, d_dists, st);
+			const int ra = absorb_shadow_profile(h);
+			if (rq == EXPANN_OK)
+				return ra;
+			if (rq != kStrictReject)
+				return h->fail(rq, h->u8_shadow->err);
+		}
+	}
 	struct {
 		ScanFn fn;
 		int tq;
@@ -831,9 +944,10 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		if (rcw != EXPANN_OK)
 			return rcw;
 		HIP_TRY(h, hipMemsetAsync(h->d_overflow + 1, 0, sizeof(uint32_t), st));
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow + 3, 0, sizeof(uint32_t), st));
 		hipLaunchKernelGGL(u8_query_prep_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, nv, h->d_q8,
-		                   h->d_overflow + 1);
+		                   h->d_overflow + 1, h->strict_u8 ? h->d_overflow + 3 : (uint32_t*)nullptr);
 		HIP_TRY(h, hipGetLastError());
 		d_queries = h->d_q8;
 	}
@@ -1349,6 +1463,8 @@ restart_direct:
 				goto restart_direct;
 			}
 		}
+		if (h->strict_u8 && (h->h_flags[1] != 0 || h->h_flags[3] != 0))
+			return kStrictReject;
 		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
 			return h->fail(EXPANN_ERR_UNSUPPORTED,
 			               std::to_string(h->h_flags[1]) +
@@ -1530,6 +1646,7 @@ void expann_destroy(expann_index* h) {
 		return;
 	hipSetDevice(h->device);
 	if (h->stream) hipStreamSynchronize(h->stream);
+	drop_u8_shadow(h);
 	if (h->owns_base && h->d_base) hipFree(h->d_base);
 	if (h->d_cand) hipFree(h->d_cand);
 	if (h->d_cnt) hipFree(h->d_cnt);
@@ -1611,6 +1728,7 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
 	if (h->owns_base && h->d_base)
 		hipFree(h->d_base);
+	drop_u8_shadow(h);
 	if (h->d_bnorm) {
 		hipFree(h->d_bnorm);
 		h->d_bnorm = nullptr;
@@ -1805,7 +1923,7 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 			HIP_TRY(h, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), h->stream));
 			hipLaunchKernelGGL(u8_query_prep_kernel, dim3((uint32_t)((h->dim + kBlock - 1) / kBlock)),
 			                   dim3(kBlock), 0, h->stream, (const float*)d_query, (size_t)h->dim,
-			                   (uint8_t*)d_q8s, d_bad);
+			                   (uint8_t*)d_q8s, d_bad, (uint32_t*)nullptr);
 			HIP_TRY(h, hipMemcpyAsync(&bad_host, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost,
 			                          h->stream));
 			qptr = d_q8s;
@@ -2265,6 +2383,9 @@ int expann_set_profiling(expann_index* h, int enable) {
 	h->profiling = enable != 0;
 	h->ev_used = 0;
 	h->prof = expann_profile{};
+	h->prof_extra_ms = 0;
+	if (h->u8_shadow)
+		return expann_set_profiling(h->u8_shadow, enable);
 	return EXPANN_OK;
 }
 
@@ -2279,10 +2400,11 @@ int expann_get_profile(expann_index* h, expann_profile* out) {
 		HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i][0], h->ev[i][1]));
 		ms += t;
 	}
-	h->prof.scan_ms = ms;
+	h->prof.scan_ms = ms + h->prof_extra_ms;
 	// (launches beyond the event pool are neither timed nor counted while profiling)
 	*out = h->prof;
 	h->ev_used = 0;
+	h->prof_extra_ms = 0;
 	h->prof = expann_profile{};
 	return EXPANN_OK;
 }
@@ -2300,6 +2422,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_scan_kernel = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
+	else if (!std::strcmp(name, "u8_exact"))
+		h->opt_u8_exact = value;
 	else if (!std::strcmp(name, "sample_run"))
 		h->opt_sample_run = value < 1 ? 1 : (value > 64 ? 64 : value);
 	else if (!std::strcmp(name, "sample_frac"))

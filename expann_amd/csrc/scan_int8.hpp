@@ -197,9 +197,12 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 }
 
 // fp32 query -> uint8 (trunc), as `uint32_t(q[i])` in src/antitopo_engine.h:726-737; values
-// outside [0,255] cannot be represented in the 8-bit kernels: *bad counts them.
+// outside [0,255] cannot be represented in the 8-bit kernels: *bad counts them.  *frac (optional)
+// counts in-range values with a fractional part (the exact-uint8 shortcut of fp32 indexes needs
+// integer queries; the uint8 engine itself truncates like the reference).
 __global__ __launch_bounds__(kBlock) void u8_query_prep_kernel(const float* q, size_t n_values,
-                                                               uint8_t* out, uint32_t* bad) {
+                                                               uint8_t* out, uint32_t* bad,
+                                                               uint32_t* frac) {
 	const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n_values)
 		return;
@@ -207,7 +210,25 @@ __global__ __launch_bounds__(kBlock) void u8_query_prep_kernel(const float* q, s
 	const bool ok = v >= 0.0f && v < 256.0f;
 	if (!ok)
 		atomicAdd(bad, 1u);
+	else if (frac && v != __builtin_truncf(v))
+		atomicAdd(frac, 1u);
 	out[i] = ok ? (uint8_t)(uint32_t)v : 0;
+}
+
+// count of values that are not integers in [0, 255] (grid-stride; one atomic per workgroup at most)
+__global__ __launch_bounds__(kBlock) void count_non_u8_kernel(const float* x, size_t n, uint32_t* bad) {
+	uint32_t c = 0;
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+		const float v = x[i];
+		c += (v >= 0.0f && v <= 255.0f && v == __builtin_truncf(v)) ? 0u : 1u;
+	}
+	if (__builtin_amdgcn_ballot_w64(c != 0) != 0 && c != 0)
+		atomicAdd(bad, c);
+}
+// fp32 (known to hold integers in [0, 255]) -> uint8
+__global__ __launch_bounds__(kBlock) void cast_f32_u8_kernel(const float* x, size_t n, uint8_t* out) {
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+		out[i] = (uint8_t)(uint32_t)x[i];
 }
 
 // scores[i] = score(query, base[ids[i]]) on 8-bit rows (cf. score_ids.hpp)

@@ -197,7 +197,10 @@ int expann_get_profile(expann_index* h, expann_profile* out);
  * 256); the final ids and distances are identical for every choice),
  * "sample_ratio" (rows ratio between the levels of the threshold ladder, default 32),
  * "sample_pass" (fp16 form: 1 = one sampled pass gives the threshold (default), 0 = ladder),
- * "sample_frac" (the sampled pass reads 1/frac of the rows; 0 = chosen from k (default)). */
+ * "sample_frac" (the sampled pass reads 1/frac of the rows; 0 = chosen from k (default)),
+ * "u8_exact" (1 (default): an fp32 L2 index of dim 128 / 256 whose values are all integers in
+ * [0, 255] keeps a uint8 copy, and batches of 8-bit integer queries are searched through the
+ * exact 8-bit kernels -- same ids and fp32 distances; 0: never). */
 int expann_set_option(expann_index* h, const char* name, long value);
 
 #ifdef __cplusplus
