@@ -314,6 +314,10 @@ def main():
     def step():
         ss.search(queries, a.k)
 
+    # one-time lazy initialisation outside any count: derived copies of the index (fp16 / uint8),
+    # workspace allocation and -- with G > 1 -- the communicators of the two process groups
+    step()
+    torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     eng.set_profiling(True)
