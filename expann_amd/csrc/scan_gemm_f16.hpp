@@ -476,6 +476,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		fb[1][0] = frag(0, 1);
 		fb[1][1] = frag(1, 1);
 		read_bn(bnv, buf);
+		// the MFMA phase outranks the other workgroup's epilogue / flush on this SIMD (+4 %)
+		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 				stage_piece(stb, srow0, pbuf, s);
 			__builtin_amdgcn_sched_barrier(0);
 		}
+		__builtin_amdgcn_s_setprio(0);
 		if (SAMPLE) {
 			// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
 			// never wins a max

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 		fb[1][0] = frag(0, 1);
 		fb[1][1] = frag(1, 1);
 		read_bp(bv, buf);
+		__builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the other workgroup's epilogue / flush
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 					stage_piece(stb, srow0, pbuf, s * PER + j);
 			__builtin_amdgcn_sched_barrier(0);
 		}
+		__builtin_amdgcn_s_setprio(0);
 		if (SAMPLE) {
 #pragma unroll
 			for (int tq = 0; tq < TQW; ++tq)
