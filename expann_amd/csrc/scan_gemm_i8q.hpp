@@ -76,7 +76,7 @@ template <int D> struct I8qGeom {
 	static constexpr int TQW = D == 768 ? 1 : 2;      // 32-query MFMA tiles per wave
 	static constexpr int WGQ = WAVES * 32 * TQW;      // queries per workgroup
 	static constexpr int NBUF = D == 768 ? 2 : 3;
-	static constexpr int QCAP = D == 768 ? 56 : kF16WaveQueue;  // queue entries per wave
+	static constexpr int QCAP = D == 768 ? 56 : 88;  // queue entries per wave
 	static constexpr bool NATURAL = D == 768;
 	static constexpr int WG_PER_CU = 512 / THREADS;
 };
