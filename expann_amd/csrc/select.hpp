@@ -309,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 	const uint32_t qi = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	uint32_t c = p.cand_cnt ? p.cand_cnt[qi] : p.fixed_count;
-	if (p.wave_done && c <= p.wave_done)
-		return;  // (uniform per workgroup)
+	if (p.wave_done && c <= p.wave_done && c <= p.cap)
+		return;  // served by a wave kernel (those leave overflowed lists, c > cap, to this one)
 	if (p.wave0_short && c <= 2048 && c <= p.cap && 8 * (size_t)p.cap >= 16384) {
 		// few queries in the launch: no separate wave kernels; wave 0 of this workgroup takes the
 		// short list, the other waves leave

@@ -162,6 +162,20 @@ def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
     eng.close()
 
 
+def test_int8_queues_overflow_retries(oracle):
+    """tiny candidate buffers: the queue form must notice the overflow, grow and repeat"""
+    rng = np.random.RandomState(99)
+    base = _sift_like(rng, 70001, 128).astype(np.uint8)
+    queries = _sift_like(rng, 130, 128).astype(np.float32)
+    eng = _engine(base, "l2", "u8")
+    eng.set_option("cand_capacity", 64)
+    eng.set_profiling(True)
+    _check(oracle, eng, base, queries, 10, oracle.METRIC_L2_U8)
+    prof = eng.get_profile()
+    assert prof["scan_kernel"].startswith("scan_gemm_i8q") and prof["retries"] >= 1
+    eng.close()
+
+
 @pytest.mark.parametrize("n,d,m,k,spread", [(20000, 128, 40, 10, 90), (4099, 64, 7, 17, 90),
                                              (3000, 128, 20, 10, 20000)])
 def test_int16_rows_refcompat(oracle, n, d, m, k, spread):
