@@ -105,6 +105,7 @@ struct expann_index {
 	size_t q_split_bytes = 0;
 	void* d_base_f16 = nullptr;      // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
 	float* d_bnorm_f16 = nullptr;    // [n] ||b||^2 (1-eps) - abs |b|
+	float* d_bns_f16 = nullptr;      // [n] ||b||^2 (1+eps) + abs |b|: the sampled pass's row term
 	float* d_qnrm = nullptr;         // [m_alloc] ||q||^2
 	float f16_scale = 0.0f;          // power of two; 0 = not built
 	float f16_bnmax = 0.0f;          // max ||b||^2 (host copy lives in d_bnmax[2])
@@ -421,8 +422,10 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	const size_t n_pad = (h->n + kF16TB - 1) / kF16TB * kF16TB;
 	HIP_TRY(h, hipMalloc(&h->d_base_f16, n_pad * h->dim * 2));
 	HIP_TRY(h, hipMalloc(&h->d_bnorm_f16, sizeof(float) * n_pad));
+	HIP_TRY(h, hipMalloc(&h->d_bns_f16, sizeof(float) * n_pad));
 	HIP_TRY(h, hipMemsetAsync(h->d_base_f16, 0, n_pad * h->dim * 2, st));
 	HIP_TRY(h, hipMemsetAsync(h->d_bnorm_f16, 0xFF, sizeof(float) * n_pad, st));  // 0xFFFFFFFF: a NaN
+	HIP_TRY(h, hipMemsetAsync(h->d_bns_f16, 0xFF, sizeof(float) * n_pad, st));
 	if (!h->d_bnmax)
 		HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
 	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 8192)),
@@ -437,6 +440,9 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(), abs_coef,
 	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16);
+	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
+	                   0, st, (const float*)nrm.p, (uint32_t)h->n, -gemm_f16_filter_eps(), -abs_coef,
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
 	h->f16_scale = scale;
@@ -1098,7 +1104,7 @@ restart_direct:
 				}
 				GemmF16Params fp{};
 				fp.base_f16 = h->d_base_f16;
-				fp.bnorm = h->d_bnorm_f16;
+				fp.bnorm = h->d_bns_f16;  // upper row term: thresholds hold row by row
 				fp.n_rows = (uint32_t)h->n;
 				fp.n_tiles_sel = t_sel;
 				fp.tile_stride = nt / t_sel;
@@ -1119,7 +1125,6 @@ restart_direct:
 				tp.m = (uint32_t)m;
 				tp.k = (uint32_t)k;
 				tp.qnrm = h->d_qnrm;
-				tp.bn_max = h->d_bnmax + 2;
 				tp.eps = gemm_f16_filter_eps();
 				tp.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
 				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
@@ -1660,6 +1665,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_bnmax) hipFree(h->d_bnmax);
 	if (h->d_base_f16) hipFree(h->d_base_f16);
 	if (h->d_bnorm_f16) hipFree(h->d_bnorm_f16);
+	if (h->d_bns_f16) hipFree(h->d_bns_f16);
 	if (h->d_qnrm) hipFree(h->d_qnrm);
 	if (h->d_sample) hipFree(h->d_sample);
 	if (h->d_base_i8q && h->base_i8q_owned) hipFree(h->d_base_i8q);
@@ -1760,6 +1766,10 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 	if (h->d_bnorm_f16) {
 		hipFree(h->d_bnorm_f16);
 		h->d_bnorm_f16 = nullptr;
+	}
+	if (h->d_bns_f16) {
+		hipFree(h->d_bns_f16);
+		h->d_bns_f16 = nullptr;
 	}
 	h->f16_scale = 0.0f;
 	h->d_base = const_cast<void*>(d_rows);

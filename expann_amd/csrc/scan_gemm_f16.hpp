@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, 
 // rows:    out = (nrm*(1-eps) - abs*sqrt(nrm)) * mul                (tau == nullptr)
 // queries: out = (tau - (nrm*(1-eps) - abs*sqrt(nrm))) * mul
 // mul = s^2/2, a power of two: the scaling is exact
+// (eps, abs_coef negated: the UPPER row term (nrm*(1+eps) + abs*sqrt(nrm)) * mul of the sampled pass)
 __global__ __launch_bounds__(kBlock) void f16_terms_kernel(const float* nrm, uint32_t n, float eps,
                                                            float abs_coef, const float* tau,
                                                            float mul, float* out) {
@@ -552,17 +553,18 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 }
 
 // tau[q] = an upper bound of the k-th smallest reference-order score over the sampled rows, from
-// the n_vals class maxima of g written by the SAMPLE pass.  The k largest maxima belong to k
-// different rows; for a row with g = q16.b16 - bn' the slack analysis at the top of this file
-// gives   score <= ||q||^2 (1+eps) - g/mul + 2 eps ||b||^2 + abs (|q| + 2|b|),   mul = s^2/2,
-// evaluated here with the largest ||b||^2 of the index.  One wave per query.
+// the n_vals class maxima of g written by the SAMPLE pass.  The SAMPLE pass subtracts the UPPER
+// row term  bns = (||b||^2 (1+eps) + abs |b|) * mul  (the full scan subtracts the lower one), so
+// for every row   score <= ||q||^2 (1+eps) + abs |q| - g/mul,   mul = s^2/2,   by the slack
+// analysis at the top of this file -- row by row, with no worst-case norm of the index in it
+// (one outlier row would otherwise inflate every threshold).  The k largest maxima belong to k
+// different rows.  One wave per query.
 struct SampleTauParams {
 	const float* vals;   // [m][n_vals]
 	uint32_t n_vals;
 	uint32_t m;
 	uint32_t k;
 	const float* qnrm;   // [m] ||q||^2
-	const float* bn_max; // [1] max ||b||^2
 	float eps, abs_coef, inv_mul;
 	float* tau;          // [m]
 	uint32_t* tau_row;   // [m] <- 0xFFFFFFFF (no row tie-break: the GEMM forms do not use it)
@@ -610,9 +612,8 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		float tau = __builtin_inff();
 		if (kth != 0) {
 			const float g = ordered_to_float((uint32_t)(kth >> 32));
-			const float qn = p.qnrm[qi], bm = p.bn_max[0];
-			tau = qn * (1.0f + p.eps) - g * p.inv_mul + 2.0f * p.eps * bm +
-			      p.abs_coef * (__builtin_sqrtf(qn) + 2.0f * __builtin_sqrtf(bm));
+			const float qn = p.qnrm[qi];
+			tau = qn * (1.0f + p.eps) + p.abs_coef * __builtin_sqrtf(qn) - g * p.inv_mul;
 			if (!(tau == tau))
 				tau = __builtin_inff();
 		}
