@@ -367,6 +367,9 @@ struct GemmVariant {
 const GemmVariant kGemmF32[] = {
     {64, scan_gemm_f32_kernel<64>, row_norms_kernel<64>, query_theta_kernel<64>, "scan_gemm_f32<64>"},
     {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
+// dims that only the fp16 form covers: a placeholder without kernels (scan == nullptr) keeps the
+// GEMM branch of the level loop alive; without the fp16 form it counts as "no GEMM form"
+const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}};
 
 using GemmBf16Fn = void (*)(GemmBf16Params);
 struct GemmBf16Variant {
@@ -392,7 +395,14 @@ const GemmF16Variant kGemmF16[] = {
     {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>,
      f16_query_prep_kernel<64>, "scan_gemm_f16<64, false>"},
     {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
-     f16_query_prep_kernel<128>, "scan_gemm_f16<128, false>"}};
+     f16_query_prep_kernel<128>, "scan_gemm_f16<128, false>"},
+    {256, scan_gemm_f16_kernel<256, false>, scan_gemm_f16_kernel<256, true>, sqnorm_kernel<256>,
+     f16_query_prep_kernel<256>, "scan_gemm_f16<256, false>"}};
+int f16_lds_bytes(int d) {
+	return d == 64 ? gemm_f16_lds_bytes<64>() : (d == 128 ? gemm_f16_lds_bytes<128>() : gemm_f16_lds_bytes<256>());
+}
+int f16_threads(int d) { return d >= 256 ? F16Geom<256>::THREADS : F16Geom<128>::THREADS; }
+int f16_wg_per_cu(int d) { return d >= 256 ? F16Geom<256>::WG_PER_CU : F16Geom<128>::WG_PER_CU; }
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
@@ -456,12 +466,16 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	// step, m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins.  fp16
 	// form (half the bytes per row, one sampled pass): 0.175 vs 0.175 ms at m = 4, 0.173 vs 0.199
 	// at m = 8, 0.185 vs 0.31 at m = 16 -- from 5 queries on it wins.
-	const bool f16_dims = (h->dim == 64 || h->dim == 128) && h->f16_scale >= 0.0f;
+	const bool f16_dims = (h->dim == 64 || h->dim == 128 || h->dim == 256) && h->f16_scale >= 0.0f;
 	if (h->opt_scan_kernel == 0 && (m < (f16_dims ? 5u : 24u) || h->n < 4096))
 		return nullptr;
 	for (const auto& v : kGemmF32)
 		if (v.d == h->dim)
 			return &v;
+	if (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4)
+		for (const auto& v : kGemmF16Only)
+			if (v.d == h->dim)
+				return &v;
 	return nullptr;
 }
 
@@ -999,11 +1013,11 @@ restart_direct:
 			if (v.d == h->dim)
 				gvf = &v;
 	if (h->opt_scan_kernel == 4 && !gvf && !no_f16)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64 or 128 only");
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64, 128 or 256 only");
 	if (gvf)
 		gvb = nullptr;
-	else if (h->opt_scan_kernel == 0 && m < 24)
-		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on
+	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))
+		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on / do not exist
 	if (gv && !gvf) {
 		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
 		if (rc != EXPANN_OK)
@@ -1090,7 +1104,7 @@ restart_direct:
 			const uint32_t run = (uint32_t)h->opt_sample_run;
 			uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 			const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-			uint32_t chunks = std::max<uint32_t>(1, (kF16WgPerCu * (uint32_t)cus) / nqt);
+			uint32_t chunks = std::max<uint32_t>(1, ((uint32_t)f16_wg_per_cu(h->dim) * (uint32_t)cus) / nqt);
 			chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 			chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
 			if (t_sel * 2 <= nt && (size_t)chunks * 32 >= 8 * k) {
@@ -1116,8 +1130,8 @@ restart_direct:
 				fp.m = (uint32_t)m;
 				fp.sample_out = h->d_sample;
 				fp.n_chunks = chunks;
-				hipLaunchKernelGGL(gvf->sample, dim3(chunks * nqt), dim3(kF16Threads),
-				                   h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>(), st, fp);
+				hipLaunchKernelGGL(gvf->sample, dim3(chunks * nqt), dim3((uint32_t)f16_threads(h->dim)),
+				                   f16_lds_bytes(h->dim), st, fp);
 				li_start = levels.size() - 1;
 				SampleTauParams tp{};
 				tp.vals = h->d_sample;
@@ -1247,7 +1261,7 @@ restart_direct:
 					fp.n_qtiles = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
 					uint32_t fchunks = 1;
 					{
-						const uint32_t slots = kF16WgPerCu * (uint32_t)cus;
+						const uint32_t slots = (uint32_t)f16_wg_per_cu(h->dim) * (uint32_t)cus;
 						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
 						double best = 1e300;
 						double best8 = 1e300;
@@ -1289,16 +1303,16 @@ restart_direct:
 						HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
 						fp.clk = clk.as<unsigned long long>();
 					}
-					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3(kF16Threads),
-					                   h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>(),
+					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)f16_threads(h->dim)),
+					                   f16_lds_bytes(h->dim),
 					                   st, fp);
 					kname = gvf->name;
 					gp.n_qtiles = fp.n_qtiles;
 					if (fp.clk) {
 						int occ = -1;
 						hipOccupancyMaxActiveBlocksPerMultiprocessor(
-						    &occ, (const void*)gvf->scan, kF16Threads,
-						    h->dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>());
+						    &occ, (const void*)gvf->scan, f16_threads(h->dim),
+						    f16_lds_bytes(h->dim));
 						std::fprintf(stderr, "scan_gemm_f16: %d workgroups per CU resident, grid %u\n", occ,
 						             fchunks * fp.n_qtiles);
 						unsigned long long c[18] = {0};
@@ -1594,10 +1608,10 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	for (const auto& v : kGemmF16)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>()) !=
+			                        f16_lds_bytes(dim)) !=
 			        hipSuccess ||
 			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        dim == 64 ? gemm_f16_lds_bytes<64>() : gemm_f16_lds_bytes<128>()) !=
+			                        f16_lds_bytes(dim)) !=
 			        hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
 				hipStreamDestroy(h->stream);

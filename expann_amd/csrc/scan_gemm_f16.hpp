@@ -210,23 +210,44 @@ constexpr int kF16Bufs = kF16Prefetch + 1;   // LDS tile buffers
 constexpr int kF16WaveQueue = 88;            // candidate queue entries per wave, in LDS
 constexpr int kF16EntryBytes = 80;
 constexpr int kF16FlushEvery = 8;            // steps between looks at the queue fill
+// Geometry by dimension (the int8 kernels use the same scheme, scan_gemm_i8q.hpp).  d = 64 / 128:
+// 4 waves x 64 queries, two workgroups per CU.  d = 256: a wave's fragments of 64 queries would
+// be 128 VGPRs, so 8 waves x 32 queries share each staged tile (one workgroup per CU), and the
+// 16-byte chunks of a row go to (k-step, lane half) in natural order (2s + h): 8 fragment
+// address registers serve all 16 k-steps.
+template <int D> struct F16Geom {
+	static constexpr int THREADS = D >= 256 ? 512 : kF16Threads;
+	static constexpr int WAVES = THREADS / 64;
+	static constexpr int TQW = D >= 256 ? 1 : 2;   // 32-query MFMA tiles per wave
+	static constexpr int WGQ = WAVES * 32 * TQW;   // queries per workgroup
+	static constexpr int NBUF = kF16Bufs;
+	static constexpr int QCAP = D >= 256 ? 56 : kF16WaveQueue;
+	static constexpr bool NATURAL = D >= 256;
+	static constexpr int WG_PER_CU = 512 / THREADS;
+};
+static_assert(F16Geom<128>::WGQ == kF16TQ && F16Geom<256>::WGQ == kF16TQ, "one query-tile size");
 template <int D> constexpr int gemm_f16_lds_bytes() {
+	using G = F16Geom<D>;
 	// tiles + per-wave bn' slots + per-wave candidate queues + theta' + queue fills
-	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) +
-	       kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 16;
+	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16;
 }
-static_assert(gemm_f16_lds_bytes<128>() * kF16WgPerCu <= 160 * 1024, "LDS budget per CU");
+static_assert(gemm_f16_lds_bytes<128>() * F16Geom<128>::WG_PER_CU <= 160 * 1024 &&
+                  gemm_f16_lds_bytes<256>() <= 160 * 1024,
+              "LDS budget per CU");
 
 template <int D, bool SAMPLE>
-__global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
-	static_assert(D == 128 || D == 64, "built for d = 64, 128");
+__global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
+	static_assert(D == 64 || D == 128 || D == 256, "built for d = 64, 128, 256");
+	using G = F16Geom<D>;
+	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
+	constexpr bool NATURAL = G::NATURAL;
 	constexpr int ROWB = D * 2;      // bytes per fp16 row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
-	constexpr int KS = D / 16;       // MFMA k-steps; lane half h of k-step s holds chunk h*KS + s
+	constexpr int KS = D / 16;       // MFMA k-steps; lane half h of k-step s: chunk h*KS + s, or 2s + h
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;  // rows per 256-byte LDS bank row
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
-	constexpr int PF = kF16Prefetch, NBUF = kF16Bufs;
+	constexpr int NBUF = G::NBUF, PF = NBUF - 1;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const int tid = threadIdx.x;
@@ -240,8 +261,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		qtile = j % p.n_qtiles;
 		chunk = (blockIdx.x & 7) + 8 * (j / p.n_qtiles);
 	}
-	const uint32_t wg_q0 = qtile * kF16TQ;
-	const uint32_t q0 = wg_q0 + wave * 64;  // this wave's 64 queries
+	const uint32_t wg_q0 = qtile * WGQ;
+	const uint32_t q0 = wg_q0 + wave * 32 * TQW;  // this wave's queries
 
 	const uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
@@ -261,15 +282,14 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		uint32_t pad;
 	};
 	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
-	QEntry* const queue =
-	    reinterpret_cast<QEntry*>(bn_slots + NBUF * kF16Waves * 256) + wave * kF16WaveQueue;
-	float* const thq = reinterpret_cast<float*>(bn_slots + NBUF * kF16Waves * 256 +
-	                                            kF16Waves * kF16WaveQueue * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + kF16TQ);
+	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * WAVES * 256) + wave * QCAP;
+	float* const thq =
+	    reinterpret_cast<float*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
 
-	f16x8 a[2][KS];
+	f16x8 a[TQW][KS];
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq) {
+	for (int tq = 0; tq < TQW; ++tq) {
 		uint32_t qi = q0 + tq * 32 + r31;
 		if (qi >= p.m)
 			qi = p.m - 1;
@@ -277,24 +297,24 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		                                                  (size_t)qi * ROWB);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			a[tq][s] = src[h * KS + s];
+			a[tq][s] = src[NATURAL ? 2 * s + h : h * KS + s];
 	}
 	// accumulator start values: theta' of the query each accumulator register belongs to
 	// (SAMPLE: they start at zero, and th holds the running class maxima of g instead)
-	f32x16 th[2];
+	f32x16 th[TQW];
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq)
+	for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 			th[tq][reg] = (qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff();
 		}
-	if (!SAMPLE)
+	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
 	// the query fragments and thresholds are in registers before the first stage load is issued:
 	// a later wait for them would be a vmcnt(0) inside the loop and drain the prefetch queue
 #pragma unroll
-	for (int tq = 0; tq < 2; ++tq) {
+	for (int tq = 0; tq < TQW; ++tq) {
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
@@ -303,10 +323,13 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	// per-lane LDS offset of k-step s (row r31 of the first column tile); the second column tile
 	// is 32 rows further, where the swizzle term is the same
 	static_assert((32 / RPB) % (SWM + 1) == 0, "swizzle must repeat every 32 rows");
-	uint32_t aoff[KS];
+	// natural order: chunk 2s + h = 16 (s >> 3) + (2 (s & 7) + h); the XOR with the row's swizzle
+	// (< 16) only touches the low part, so 8 registers + immediates address every k-step
+	constexpr int NA = NATURAL ? 8 : KS;
+	uint32_t aoff[NA];
 #pragma unroll
-	for (int s = 0; s < KS; ++s)
-		aoff[s] = r31 * ROWB + (((h * KS + s) ^ ((r31 / RPB) & SWM)) * 16);
+	for (int j = 0; j < NA; ++j)
+		aoff[j] = r31 * ROWB + (((NATURAL ? 2 * j + h : h * KS + j) ^ ((r31 / RPB) & SWM)) * 16);
 
 	auto tile_row0 = [&](uint32_t t) -> uint32_t {
 		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kF16TB;
@@ -316,31 +339,36 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	// the bn' of the 64 rows into a slot of its own), every step, with no branches -- the last
 	// steps re-stage the final tile into a free buffer -- so the stage loads sit in the same
 	// basic block as the MFMAs and the vmcnt arithmetic is a constant.
-	constexpr int ROWS_PER_INSTR = kF16Threads / CH;
-	static_assert(ROWS_PER_INSTR % (16 * RPB) == 0, "swizzle must be instruction-invariant");
-	constexpr int N_STAGE = kF16TB * CH / kF16Threads;
+	// piece i of a thread is slot S = i*THREADS + tid of the tile (16 bytes each, LDS order =
+	// row-major physical chunks); its source is the logical chunk pc ^ swizzle(row)
+	constexpr int N_STAGE = kF16TB * CH / THREADS;
+	static_assert(kF16TB * CH % THREADS == 0, "whole staging rounds");
 	constexpr int LOADS = N_STAGE + 1;
-	const uint32_t lane_row = tid / CH;
-	const uint32_t lane_off = lane_row * ROWB + (((tid % CH) ^ ((lane_row / RPB) & SWM)) * 16);
+	uint32_t soff[N_STAGE];
+#pragma unroll
+	for (int i = 0; i < N_STAGE; ++i) {
+		const uint32_t S = i * THREADS + tid;
+		const uint32_t r = S / CH, pc = S % CH;
+		soff[i] = r * ROWB + ((pc ^ ((r / RPB) & SWM)) * 16);
+	}
 	// piece i of a tile's stage: i < N_STAGE the wave's i-th 1 KiB of the tile, i == N_STAGE the bn'
 	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
 		if (i < N_STAGE) {
 			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
 			__builtin_amdgcn_global_load_lds(
-			    (const __attribute__((address_space(1))) void*)(tb + (uint32_t)i * ROWS_PER_INSTR * ROWB),
-			    (__attribute__((address_space(3))) void*)(dst0 + i * kF16Threads * 16), 16, 0, 0);
+			    (const __attribute__((address_space(1))) void*)(tb + soff[i < N_STAGE ? i : 0]),
+			    (__attribute__((address_space(3))) void*)(dst0 + i * THREADS * 16), 16, 0, 0);
 		} else {
 			__builtin_amdgcn_global_load_lds(
 			    (const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
-			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * kF16Waves + wave) * 256), 4, 0,
-			    0);
+			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * WAVES + wave) * 256), 4, 0, 0);
 		}
 	};
 	auto stage_src = [&](uint32_t t, uint32_t& row0) -> const unsigned char* {
 		if (t > t1 - 1)
 			t = t1 - 1;
 		row0 = tile_row0(t);
-		return (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB + lane_off;
+		return (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB;
 	};
 	auto stage = [&](uint32_t t, int buf) {
 		uint32_t row0;
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 			stage_piece(tb, row0, buf, i);
 	};
 	auto read_bn = [&](float (&bnv)[2], int buf) {
-		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * kF16Waves + wave) * 256);
+		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * WAVES + wave) * 256);
 		bnv[0] = slot[r31];
 		bnv[1] = slot[32 + r31];
 	};
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	};
 	// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
 	auto flush_own = [&]() {
-		const uint32_t n = wfill < (uint32_t)kF16WaveQueue ? wfill : (uint32_t)kF16WaveQueue;
+		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		constexpr int R = 8;
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 				const float c = e.acc[reg], bn = e.bn;
 				hit[j] = i < n * 16 && c >= bn;
 				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
-				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (kF16TQ - 1)]) * p.two_inv_s2, e.row);
+				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (WGQ - 1)]) * p.two_inv_s2, e.row);
 			}
 #pragma unroll
 			for (int j = 0; j < R; ++j)
@@ -396,9 +424,9 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		}
 		wfill = 0;
 	};
-	auto epilogue = [&](const f32x16 (&accs)[2][2], uint32_t row0, const float (&bnv)[2]) {
+	auto epilogue = [&](const f32x16 (&accs)[TQW][2], uint32_t row0, const float (&bnv)[2]) {
 #pragma unroll
-		for (int tq = 0; tq < 2; ++tq)
+		for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 			for (int tc = 0; tc < 2; ++tc) {
 				const f32x16& c = accs[tq][tc];
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 					    wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
 					                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 					if (m0 >= bn) {
-						if (slot < (uint32_t)kF16WaveQueue) {
+						if (slot < (uint32_t)QCAP) {
 							QEntry& e = queue[slot];
 #pragma unroll
 							for (int reg = 0; reg < 16; ++reg)
@@ -452,7 +480,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 		stage(t0 + i, i);
 	wait_vm_then_barrier<(PF - 1) * LOADS>();  // tile t0 landed, thq visible
 
-	f32x16 acc[2][2];
+	f32x16 acc[TQW][2];
 	f32x16 zero16;
 #pragma unroll
 	for (int e = 0; e < 16; ++e)
@@ -463,7 +491,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	for (uint32_t t = t0; t < t1; ++t) {
 		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int tc, int s) -> f16x8 {
-			return *reinterpret_cast<const f16x8*>(smem + (boff + aoff[s]) + tc * 32 * ROWB);
+			const uint32_t o = NATURAL ? aoff[s & 7] + (s >> 3) * 256 : aoff[NATURAL ? 0 : s];
+			return *reinterpret_cast<const f16x8*>(smem + (boff + o) + tc * 32 * ROWB);
 		};
 		// Order pinned by scheduling barriers: the fragments of k-step s+2 are requested before
 		// the MFMAs of k-step s issue, and the stage loads of tile t+PF go out one per k-step,
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 				}
 			}
 #pragma unroll
-			for (int tq = 0; tq < 2; ++tq) {
+			for (int tq = 0; tq < TQW; ++tq) {
 				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
 				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
 				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 			// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
 			// never wins a max
 #pragma unroll
-			for (int tq = 0; tq < 2; ++tq)
+			for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 				for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
@@ -525,8 +554,8 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 				wait_vm_then_barrier<(PF - 1) * LOADS>();
 			if (look) {
 				since_look = 0;
-				const uint32_t f = fills[lane & (kF16Waves - 1)];
-				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)kF16WaveQueue / 2) != 0)
+				const uint32_t f = fills[lane & (WAVES - 1)];
+				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
 					flush_own();
 			}
 		}
@@ -535,7 +564,7 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16_kernel(GemmF16Pa
 	}
 	if (SAMPLE) {
 #pragma unroll
-		for (int tq = 0; tq < 2; ++tq)
+		for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
 			for (int reg = 0; reg < 16; ++reg) {
 				const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
