@@ -369,7 +369,7 @@ const GemmVariant kGemmF32[] = {
     {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
 // dims that only the fp16 form covers: a placeholder without kernels (scan == nullptr) keeps the
 // GEMM branch of the level loop alive; without the fp16 form it counts as "no GEMM form"
-const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}};
+const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}, {512, nullptr, nullptr, nullptr, "-"}};
 
 using GemmBf16Fn = void (*)(GemmBf16Params);
 struct GemmBf16Variant {
@@ -397,9 +397,13 @@ const GemmF16Variant kGemmF16[] = {
     {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
      f16_query_prep_kernel<128>, "scan_gemm_f16<128, false>"},
     {256, scan_gemm_f16_kernel<256, false>, scan_gemm_f16_kernel<256, true>, sqnorm_kernel<256>,
-     f16_query_prep_kernel<256>, "scan_gemm_f16<256, false>"}};
+     f16_query_prep_kernel<256>, "scan_gemm_f16<256, false>"},
+    {512, scan_gemm_f16_kernel<512, false>, scan_gemm_f16_kernel<512, true>, sqnorm_kernel<512>,
+     f16_query_prep_kernel<512>, "scan_gemm_f16<512, false>"}};
 int f16_lds_bytes(int d) {
-	return d == 64 ? gemm_f16_lds_bytes<64>() : (d == 128 ? gemm_f16_lds_bytes<128>() : gemm_f16_lds_bytes<256>());
+	return d == 64 ? gemm_f16_lds_bytes<64>()
+	               : (d == 128 ? gemm_f16_lds_bytes<128>()
+	                           : (d == 256 ? gemm_f16_lds_bytes<256>() : gemm_f16_lds_bytes<512>()));
 }
 int f16_threads(int d) { return d >= 256 ? F16Geom<256>::THREADS : F16Geom<128>::THREADS; }
 int f16_wg_per_cu(int d) { return d >= 256 ? F16Geom<256>::WG_PER_CU : F16Geom<128>::WG_PER_CU; }
@@ -466,7 +470,7 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	// step, m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins.  fp16
 	// form (half the bytes per row, one sampled pass): 0.175 vs 0.175 ms at m = 4, 0.173 vs 0.199
 	// at m = 8, 0.185 vs 0.31 at m = 16 -- from 5 queries on it wins.
-	const bool f16_dims = (h->dim == 64 || h->dim == 128 || h->dim == 256) && h->f16_scale >= 0.0f;
+	const bool f16_dims = (h->dim == 64 || h->dim == 128 || h->dim == 256 || h->dim == 512) && h->f16_scale >= 0.0f;
 	if (h->opt_scan_kernel == 0 && (m < (f16_dims ? 5u : 24u) || h->n < 4096))
 		return nullptr;
 	for (const auto& v : kGemmF32)
@@ -1013,7 +1017,7 @@ restart_direct:
 			if (v.d == h->dim)
 				gvf = &v;
 	if (h->opt_scan_kernel == 4 && !gvf && !no_f16)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64, 128 or 256 only");
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64, 128, 256 or 512 only");
 	if (gvf)
 		gvb = nullptr;
 	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))

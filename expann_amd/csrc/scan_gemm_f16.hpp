@@ -220,8 +220,8 @@ template <int D> struct F16Geom {
 	static constexpr int WAVES = THREADS / 64;
 	static constexpr int TQW = D >= 256 ? 1 : 2;   // 32-query MFMA tiles per wave
 	static constexpr int WGQ = WAVES * 32 * TQW;   // queries per workgroup
-	static constexpr int NBUF = kF16Bufs;
-	static constexpr int QCAP = D >= 256 ? 56 : kF16WaveQueue;
+	static constexpr int NBUF = D >= 512 ? 2 : kF16Bufs;  // d = 512: two 64 KB tile buffers
+	static constexpr int QCAP = D >= 512 ? 32 : (D >= 256 ? 56 : kF16WaveQueue);
 	static constexpr bool NATURAL = D >= 256;
 	static constexpr int WG_PER_CU = 512 / THREADS;
 };
@@ -232,12 +232,12 @@ template <int D> constexpr int gemm_f16_lds_bytes() {
 	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16;
 }
 static_assert(gemm_f16_lds_bytes<128>() * F16Geom<128>::WG_PER_CU <= 160 * 1024 &&
-                  gemm_f16_lds_bytes<256>() <= 160 * 1024,
+                  gemm_f16_lds_bytes<256>() <= 160 * 1024 && gemm_f16_lds_bytes<512>() <= 160 * 1024,
               "LDS budget per CU");
 
 template <int D, bool SAMPLE>
 __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
-	static_assert(D == 64 || D == 128 || D == 256, "built for d = 64, 128, 256");
+	static_assert(D == 64 || D == 128 || D == 256 || D == 512, "built for d = 64, 128, 256, 512");
 	using G = F16Geom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
 	constexpr bool NATURAL = G::NATURAL;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 	// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		constexpr int R = 8;
+		constexpr int R = D >= 512 ? 4 : 8;
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
 			uint32_t qi[R], slot[R];
@@ -500,24 +500,26 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
 		static_assert(LOADS <= KS, "one stage piece per k-step");
+		constexpr int FD = D >= 512 ? 1 : 2;  // k-steps of fragment read-ahead (d = 512: registers)
 		f16x8 fb[KS][2];
-		fb[0][0] = frag(0, 0);
-		fb[0][1] = frag(1, 0);
-		fb[1][0] = frag(0, 1);
-		fb[1][1] = frag(1, 1);
+#pragma unroll
+		for (int s = 0; s < FD; ++s) {
+			fb[s][0] = frag(0, s);
+			fb[s][1] = frag(1, s);
+		}
 		read_bn(bnv, buf);
 		// the MFMA phase outranks the other workgroup's epilogue / flush on this SIMD (+4 %)
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
-			if (s + 2 < KS) {  // two k-steps ahead: a wait for k-step s+1 never meets a fresh request
+			if (s + FD < KS) {  // FD k-steps ahead: a wait for k-step s+1 never meets a fresh request
 				if (p.debug & 32) {
-					fb[s + 2][0] = fb[0][0];
-					fb[s + 2][1] = fb[0][1];
+					fb[s + FD][0] = fb[0][0];
+					fb[s + FD][1] = fb[0][1];
 				} else {
-					fb[s + 2][0] = frag(0, s + 2);
-					fb[s + 2][1] = frag(1, s + 2);
+					fb[s + FD][0] = frag(0, s + FD);
+					fb[s + FD][1] = frag(1, s + FD);
 				}
 			}
 #pragma unroll
