@@ -369,7 +369,8 @@ const GemmVariant kGemmF32[] = {
     {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
 // dims that only the fp16 form covers: a placeholder without kernels (scan == nullptr) keeps the
 // GEMM branch of the level loop alive; without the fp16 form it counts as "no GEMM form"
-const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}, {512, nullptr, nullptr, nullptr, "-"}};
+const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}, {512, nullptr, nullptr, nullptr, "-"},
+                                    {64, nullptr, nullptr, nullptr, "-"}, {128, nullptr, nullptr, nullptr, "-"}};
 
 using GemmBf16Fn = void (*)(GemmBf16Params);
 struct GemmBf16Variant {
@@ -451,12 +452,13 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(1024), 0, st, (const float*)nrm.p, h->n,
 	                   h->d_bnmax + 2);
 	const float abs_coef = std::ldexp(1.0f, -24) / scale * std::sqrt((float)h->dim);
+	const int ipm = h->metric == EXPANN_METRIC_IP ? 1 : 0;
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(), abs_coef,
-	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16);
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16, ipm);
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, -gemm_f16_filter_eps(), -abs_coef,
-	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16);
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16, ipm);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
 	h->f16_scale = scale;
@@ -464,8 +466,18 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 }
 
 const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
-	if (h->opt_scan_kernel == 1 || h->metric != EXPANN_METRIC_L2 || h->dtype != EXPANN_DTYPE_F32)
+	if (h->opt_scan_kernel == 1 || h->dtype != EXPANN_DTYPE_F32)
 		return nullptr;
+	if (h->metric == EXPANN_METRIC_IP) {
+		// inner product: only the fp16 form has it (a placeholder variant keeps the GEMM branch alive)
+		const bool ok = (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4) && h->f16_scale >= 0.0f &&
+		                !(h->opt_scan_kernel == 0 && (m < 5 || h->n < 4096));
+		if (ok)
+			for (const auto& v : kGemmF16Only)
+				if (v.d == h->dim)
+					return &v;
+		return nullptr;
+	}
 	// measured crossovers at N = 1M, d = 128.  bf16x3 / fp32 forms: m = 16: 0.34 vs 0.37 ms per
 	// step, m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins.  fp16
 	// form (half the bytes per row, one sampled pass): 0.175 vs 0.175 ms at m = 4, 0.173 vs 0.199
@@ -1146,6 +1158,7 @@ restart_direct:
 				tp.eps = gemm_f16_filter_eps();
 				tp.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
 				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
+				tp.ip = ip ? 1 : 0;
 				tp.tau = h->d_tau[(li_start + 1) & 1];
 				tp.tau_row = h->d_tau_row[(li_start + 1) & 1];
 				tp.theta = h->d_theta;
@@ -1202,7 +1215,7 @@ restart_direct:
 					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
 					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
 					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau,
-					                   0.5f * h->f16_scale * h->f16_scale, h->d_theta);
+					                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0);
 				else
 					hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 					                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
@@ -1295,7 +1308,7 @@ restart_direct:
 					fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
 					fp.queries_f16 = h->d_q_split;
 					fp.theta = gp.theta;
-					fp.two_inv_s2 = 2.0f / (h->f16_scale * h->f16_scale);
+					fp.two_inv_s2 = (ip ? 1.0f : 2.0f) / (h->f16_scale * h->f16_scale);
 					fp.m = gp.m;
 					fp.cand_cnt = gp.cand_cnt;
 					fp.cand = gp.cand;
@@ -1449,11 +1462,14 @@ restart_direct:
 			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
 			sel.dim = (uint32_t)h->dim;
 			sel.metric_ip = ip ? 1u : 0u;
-			sel.prune_eps = use_gemm ? (gvf ? 2.0f * gemm_f16_filter_eps()
+			// (inner product, fp16 form only: the approximate key is off by at most E_q + E_b in
+			// total, half the L2 margins)
+			const float pr = ip ? 1.0f : 2.0f;
+			sel.prune_eps = use_gemm ? (gvf ? pr * gemm_f16_filter_eps()
 			                                : (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)))
 			                         : 0.0f;
 			sel.prune_abs = (use_gemm && gvf)
-			                    ? 2.0f * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
+			                    ? pr * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
 			                    : 0.0f;
 			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
 			sel.overflow = h->d_overflow;

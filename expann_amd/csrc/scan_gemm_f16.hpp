@@ -147,13 +147,23 @@ __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, 
 // queries: out = (tau - (nrm*(1-eps) - abs*sqrt(nrm))) * mul
 // mul = s^2/2, a power of two: the scaling is exact
 // (eps, abs_coef negated: the UPPER row term (nrm*(1+eps) + abs*sqrt(nrm)) * mul of the sampled pass)
+//
+// Inner product (score = -q.b, ip != 0): |q.b - q16.b16/s^2| <= E/2 with the same
+// E = eps (||q||^2 + ||b||^2) + abs (|q| + |b|), so with e(v) = eps v + abs sqrt(v):
+//   rows:    out = -e(nrm) * mul          queries: out = (2 tau + e(nrm)) * mul
+// and the kernel's test acc = theta' + q16.b16 >= bn' keeps every row with -q.b <= tau.
 __global__ __launch_bounds__(kBlock) void f16_terms_kernel(const float* nrm, uint32_t n, float eps,
                                                            float abs_coef, const float* tau,
-                                                           float mul, float* out) {
+                                                           float mul, float* out, int ip) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n)
 		return;
 	const float v = nrm[i];
+	if (ip) {
+		const float e = v * eps + abs_coef * __builtin_sqrtf(v);
+		out[i] = (tau ? 2.0f * tau[i] + e : -e) * mul;
+		return;
+	}
 	const float t = v * (1.0f - eps) - abs_coef * __builtin_sqrtf(v);
 	out[i] = (tau ? tau[i] - t : t) * mul;
 }
@@ -169,7 +179,7 @@ struct GemmF16Params {
 	uint32_t n_qtiles;
 	const void* queries_f16; // [m][D] fp16, scaled by s
 	const float* theta;      // [m] (tau - ||q||^2 (1-eps) + abs*|q|) * s^2/2
-	float two_inv_s2;        // 2 / s^2 (exact: s is a power of two)
+	float two_inv_s2;        // 2 / s^2 (exact: s is a power of two); inner product: 1 / s^2
 	uint32_t m;
 	uint32_t* cand_cnt;
 	uint64_t* cand;
@@ -597,6 +607,7 @@ struct SampleTauParams {
 	uint32_t k;
 	const float* qnrm;   // [m] ||q||^2
 	float eps, abs_coef, inv_mul;
+	int ip;              // inner product: score <= e(||q||^2)/2 - g/s^2 (the SAMPLE pass subtracts +e(||b||^2) mul)
 	float* tau;          // [m]
 	uint32_t* tau_row;   // [m] <- 0xFFFFFFFF (no row tie-break: the GEMM forms do not use it)
 	float* theta;        // [m] <- (tau - (||q||^2 (1-eps) - abs |q|)) * mul, as f16_terms_kernel
@@ -644,14 +655,18 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		if (kth != 0) {
 			const float g = ordered_to_float((uint32_t)(kth >> 32));
 			const float qn = p.qnrm[qi];
-			tau = qn * (1.0f + p.eps) + p.abs_coef * __builtin_sqrtf(qn) - g * p.inv_mul;
+			if (p.ip)
+				tau = 0.5f * (qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) - g * (0.5f * p.inv_mul);
+			else
+				tau = qn * (1.0f + p.eps) + p.abs_coef * __builtin_sqrtf(qn) - g * p.inv_mul;
 			if (!(tau == tau))
 				tau = __builtin_inff();
 		}
 		p.tau[qi] = tau;
 		p.tau_row[qi] = 0xFFFFFFFFu;
 		const float qn = p.qnrm[qi];
-		p.theta[qi] = (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
+		p.theta[qi] = p.ip ? (2.0f * tau + qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) * p.mul
+		                   : (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
 		p.cand_cnt[qi] = 0;
 	}
 }

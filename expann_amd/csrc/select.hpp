@@ -205,7 +205,7 @@ __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint
 	const uint32_t l = lane & 15, grp = lane >> 4;  // 16 lanes per candidate row
 	const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
 	float cutoff = __builtin_inff();
-	if (p.prune_eps > 0.0f && !p.metric_ip && c > p.k) {
+	if (p.prune_eps > 0.0f && c > p.k) {
 		float qn = 0.0f;
 		for (uint32_t t = 0; t < p.dim / 16; ++t)
 			qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void select_topk_kernel(SelectParams p) {
 		const uint32_t l = tid & 15, grp = tid >> 4;  // 16 lanes per candidate row
 		const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
 		uint32_t n_rescore = c;
-		if (p.prune_eps > 0.0f && !p.metric_ip && c > p.k) {
+		if (p.prune_eps > 0.0f && c > p.k) {
 			// order by the approximate key, keep what can still reach the k best
 			bitonic(n2);
 			float qn = 0.0f;
