@@ -126,7 +126,7 @@ def _grid_worker(rank, world, row_shards, port, n, d, m, k, out):
 
 
 @pytest.mark.parametrize("world,row_shards,m", [(4, None, 10), (4, 4, 9), (2, None, 7), (6, 2, 10),
-                                                (3, None, 5)])
+                                                (3, None, 5), (2, 1, 7)])
 def test_grid_sharded_search_matches_unsharded(world, row_shards, m):
     """rows x queries grid (bench.py's default layout): every rank must end with the full,
     unsharded answer, ragged query slices included."""
