@@ -558,6 +558,10 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 		} else {
 			if (!(p.debug & 4))
 				epilogue(acc, tile_row0(t), bnv);
+			// a queue about to overflow is emptied at once (dense hits: few workgroups, loose
+			// thresholds); the slow straight-to-the-lists path stays a last resort
+			if (wfill >= (uint32_t)QCAP * 3 / 4)
+				flush_own();
 			const bool look = ++since_look == kF16FlushEvery;
 			if (look && lane == 0)
 				fills[wave] = wfill;

@@ -380,6 +380,8 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 			wait_vm_then_barrier<(PF - 1) * LOADS>();
 		} else {
 			epilogue(acc, tile_row0(t), bv);
+			if (wfill >= (uint32_t)QCAP * 3 / 4)  // about to overflow: empty it at once
+				flush_own();
 			const bool look = ++since_look == kF16FlushEvery;
 			if (look && lane == 0)
 				fills[wave] = wfill;
