@@ -1336,13 +1336,6 @@ restart_direct:
 						HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
 						std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
 						             c[1] / 100.0, c[1] ? c[0] * 100.0 / c[1] : 0.0);
-						for (int w = 0; w < 2; ++w) {
-							std::fprintf(stderr, "  wave %d step 100 stamps (top, staged, pre-epi, mfma issued, epi, "
-							                     "barrier, flush):", w * 2);
-							for (int i = 0; i < 7; ++i)
-								std::fprintf(stderr, " %lld", (long long)(c[2 + w * 8 + i] - c[2]));
-							std::fprintf(stderr, "\n");
-						}
 					}
 				} else if (gvb) {
 					GemmBf16Params bp{};
