@@ -8,7 +8,7 @@
 // This is NOT a reduced-precision result: the filter only has to keep every row whose
 // reference-order score is <= tau_q, and it does so with a slack that covers the dropped terms
 // (ql.bl and the split residuals, <= 3*2^-18 |q_i b_i| per element), the fp32 accumulation of
-// the 3d products and everything the fp32 GEMM form already budgets (DESIGN.md 4.4):
+// the 3d products and everything the fp32 GEMM form already budgets (DESIGN.md 4.2):
 //      eps = (10 d + 512) * 2^-24      (needed: ~(4d + 226) * 2^-24; the rest is margin for the
 //                                       matrix core's internal summation order)
 // Survivors are re-scored in the reference's exact 16-lane FMA order by the select kernel, so

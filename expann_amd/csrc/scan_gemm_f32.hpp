@@ -8,7 +8,7 @@
 //
 // in the epilogue.  (*) is the reference's squared-L2 test  dist2(q,b) <= tau_q  written in
 // expanded form with a slack eps = (4d+128) * 2^-24 that dominates every rounding error of the
-// expanded evaluation AND of the reference-order evaluation (DESIGN.md 4.4), so every row whose
+// expanded evaluation AND of the reference-order evaluation (DESIGN.md 4.2), so every row whose
 // reference-order score is <= tau_q survives.  Survivors are only CANDIDATES: the select kernel
 // re-scores them in the reference's exact 16-lane FMA order (select.hpp, rerank) before the
 // (score, id) selection, so the final ids and distances are bit-identical to the direct scan.
