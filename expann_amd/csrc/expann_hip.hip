@@ -991,6 +991,8 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 	                   ? (uint32_t)h->opt_cand_capacity
 	                   : pow2ceil((uint32_t)std::max<size_t>(2048, 64 * k));
 	cap = std::min(pow2ceil(cap), kMaxCap);
+	if (h->opt_cand_capacity > 0 && (size_t)cap < 2 * k)  // the option is a starting size, never below 2k
+		cap = std::min(pow2ceil((uint32_t)(2 * k)), kMaxCap);
 	if ((size_t)cap < 2 * k)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "k too large for the candidate buffers (k <= " +
 		                                           std::to_string(kMaxCap / 2) + ")");
