@@ -605,7 +605,9 @@ int i8q_lds_bytes(int d) {
 	return d == 128 ? gemm_i8q_lds_bytes<128>() : (d == 256 ? gemm_i8q_lds_bytes<256>() : gemm_i8q_lds_bytes<768>());
 }
 int i8q_threads(int d) { return d == 768 ? I8qGeom<768>::THREADS : I8qGeom<128>::THREADS; }
-int i8q_wg_per_cu(int d) { return d == 768 ? I8qGeom<768>::WG_PER_CU : I8qGeom<128>::WG_PER_CU; }
+int i8q_wg_per_cu(int d) {
+	return d == 768 ? I8qGeom<768>::WG_PER_CU : (d == 256 ? I8qGeom<256>::WG_PER_CU : I8qGeom<128>::WG_PER_CU);
+}
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
 constexpr int kStrictReject = -1001;  // internal (uint8 shadow): these queries are not 8-bit integers
 

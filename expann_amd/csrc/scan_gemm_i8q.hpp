@@ -76,21 +76,28 @@ template <int D> struct I8qGeom {
 	static constexpr int TQW = D == 768 ? 1 : 2;      // 32-query MFMA tiles per wave
 	static constexpr int WGQ = WAVES * 32 * TQW;      // queries per workgroup
 	static constexpr int NBUF = D == 768 ? 2 : 3;
-	static constexpr int QCAP = D == 768 ? 56 : 88;  // queue entries per wave
+	// d = 128: the query fragments are only 32 VGPRs; with the accumulator start values read from
+	// LDS at every step instead of held in 32 more, the scan fits 168 VGPRs and THREE workgroups
+	// share a CU (3 waves per SIMD to cover each other's barriers and flushes)
+	static constexpr bool TH_LDS = D == 128;
+	static constexpr int QCAP = D == 768 ? 56 : (TH_LDS ? 56 : 88);  // queue entries per wave
 	static constexpr bool NATURAL = D == 768;
-	static constexpr int WG_PER_CU = 512 / THREADS;
+	static constexpr int WG_PER_CU = TH_LDS ? 3 : 512 / THREADS;
 };
 static_assert(I8qGeom<128>::WGQ == kF16TQ && I8qGeom<768>::WGQ == kF16TQ, "one query-tile size");
 
 template <int D> constexpr int gemm_i8q_lds_bytes() {
 	using G = I8qGeom<D>;
-	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16;
+	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16 +
+	       (G::TH_LDS ? G::WAVES * 2 * G::TQW * 16 * 4 : 0);
 }
-static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<256>() * 2 <= 160 * 1024,
+static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<256>() * 2 <= 160 * 1024 &&
+                  gemm_i8q_lds_bytes<128>() * 3 <= 160 * 1024,
               "LDS budget per CU");
 
 template <int D, bool L2FORM, bool SAMPLE>
-__global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(GemmI8qParams p) {
+__global__ __launch_bounds__(I8qGeom<D>::THREADS, (I8qGeom<D>::TH_LDS && !SAMPLE) ? 3 : 2) void
+scan_gemm_i8q_kernel(GemmI8qParams p) {
 	static_assert(D == 128 || D == 256 || D == 768, "built for d = 128, 256, 768");
 	using G = I8qGeom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
@@ -138,6 +145,9 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 	int* const thq =
 	    reinterpret_cast<int*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
 	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
+	constexpr bool THL = G::TH_LDS && !SAMPLE;
+	// (THL) accumulator start values by (wave, lane half): 16 per query tile, read back as broadcasts
+	int* const thl = reinterpret_cast<int*>(fills + 4) + (wave * 2 + h) * (TQW * 16);
 
 	constexpr int kNever = -2147483647 - 1;
 	// query fragments; lane half h of k-step s holds chunk 2s + h (natural) or h*KS + s
@@ -165,12 +175,20 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 		}
 	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.thp[wg_q0 + tid] : kNever / 2;
+	if (THL && r31 == 0) {
+#pragma unroll
+		for (int tq = 0; tq < TQW; ++tq)
+#pragma unroll
+			for (int reg = 0; reg < 16; ++reg)
+				thl[tq * 16 + reg] = th[tq][reg];
+	}
 #pragma unroll
 	for (int tq = 0; tq < TQW; ++tq) {
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
-		asm volatile("" : "+v"(th[tq]));
+		if (!THL)
+			asm volatile("" : "+v"(th[tq]));
 	}
 	// LDS offsets of this lane's fragment chunks (row r31 of the first column tile; the second
 	// is 32 rows further, same swizzle term).  Natural order: chunk 2s + h = 16 (s >> 3) +
@@ -355,6 +373,14 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8q_kernel(G
 			}
 #pragma unroll
 			for (int tq = 0; tq < TQW; ++tq) {
+				if (THL && s == 0) {
+					// start values straight from LDS into the first accumulator, which then seeds
+					// both column tiles (second one first: the first is overwritten in place)
+					acc[tq][0] = *reinterpret_cast<const i32x16*>(thl + tq * 16);
+					acc[tq][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[tq][s], fb[s][1], acc[tq][0], 0, 0, 0);
+					acc[tq][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[tq][s], fb[s][0], acc[tq][0], 0, 0, 0);
+					continue;
+				}
 				acc[tq][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
 				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
 				acc[tq][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
