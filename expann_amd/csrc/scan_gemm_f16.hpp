@@ -231,22 +231,28 @@ template <int D> struct F16Geom {
 	static constexpr int TQW = D >= 256 ? 1 : 2;   // 32-query MFMA tiles per wave
 	static constexpr int WGQ = WAVES * 32 * TQW;   // queries per workgroup
 	static constexpr int NBUF = D >= 512 ? 2 : kF16Bufs;  // d = 512: two 64 KB tile buffers
-	static constexpr int QCAP = D >= 512 ? 32 : (D >= 256 ? 56 : kF16WaveQueue);
+	// d = 64: fragments of 64 queries are 32 VGPRs; with the accumulator start values read from
+	// LDS each step the scan fits 168 VGPRs and THREE workgroups share a CU (as I8qGeom<128>)
+	static constexpr bool TH_LDS = D == 64;
+	static constexpr int QCAP = D >= 512 ? 32 : ((D >= 256 || TH_LDS) ? 56 : kF16WaveQueue);
 	static constexpr bool NATURAL = D >= 256;
-	static constexpr int WG_PER_CU = 512 / THREADS;
+	static constexpr int WG_PER_CU = TH_LDS ? 3 : 512 / THREADS;
 };
 static_assert(F16Geom<128>::WGQ == kF16TQ && F16Geom<256>::WGQ == kF16TQ, "one query-tile size");
 template <int D> constexpr int gemm_f16_lds_bytes() {
 	using G = F16Geom<D>;
 	// tiles + per-wave bn' slots + per-wave candidate queues + theta' + queue fills
-	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16;
+	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16 +
+	       (G::TH_LDS ? G::WAVES * 2 * G::TQW * 16 * 4 : 0);
 }
-static_assert(gemm_f16_lds_bytes<128>() * F16Geom<128>::WG_PER_CU <= 160 * 1024 &&
+static_assert(gemm_f16_lds_bytes<64>() * 3 <= 160 * 1024 &&
+                  gemm_f16_lds_bytes<128>() * F16Geom<128>::WG_PER_CU <= 160 * 1024 &&
                   gemm_f16_lds_bytes<256>() <= 160 * 1024 && gemm_f16_lds_bytes<512>() <= 160 * 1024,
               "LDS budget per CU");
 
 template <int D, bool SAMPLE>
-__global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
+__global__ __launch_bounds__(F16Geom<D>::THREADS, (F16Geom<D>::TH_LDS && !SAMPLE) ? 3 : 2) void
+scan_gemm_f16_kernel(GemmF16Params p) {
 	static_assert(D == 64 || D == 128 || D == 256 || D == 512, "built for d = 64, 128, 256, 512");
 	using G = F16Geom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
@@ -296,6 +302,9 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 	float* const thq =
 	    reinterpret_cast<float*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
 	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
+	constexpr bool THL = G::TH_LDS && !SAMPLE;
+	// (THL) accumulator start values by (wave, lane half): 16 per query tile, read back as broadcasts
+	float* const thl = reinterpret_cast<float*>(fills + 4) + (wave * 2 + h) * (TQW * 16);
 
 	f16x8 a[TQW][KS];
 #pragma unroll
@@ -321,6 +330,13 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 		}
 	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
+	if (THL && r31 == 0) {
+#pragma unroll
+		for (int tq = 0; tq < TQW; ++tq)
+#pragma unroll
+			for (int reg = 0; reg < 16; ++reg)
+				thl[tq * 16 + reg] = th[tq][reg];
+	}
 	// the query fragments and thresholds are in registers before the first stage load is issued:
 	// a later wait for them would be a vmcnt(0) inside the loop and drain the prefetch queue
 #pragma unroll
@@ -328,7 +344,8 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
-		asm volatile("" : "+v"(th[tq]));
+		if (!THL)
+			asm volatile("" : "+v"(th[tq]));
 	}
 	// per-lane LDS offset of k-step s (row r31 of the first column tile); the second column tile
 	// is 32 rows further, where the swizzle term is the same
@@ -534,6 +551,14 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(G
 			}
 #pragma unroll
 			for (int tq = 0; tq < TQW; ++tq) {
+				if (THL && s == 0) {
+					// start values straight from LDS into the first accumulator, which then seeds
+					// both column tiles (second one first: the first is overwritten in place)
+					acc[tq][0] = *reinterpret_cast<const f32x16*>(thl + tq * 16);
+					acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][1], acc[tq][0], 0, 0, 0);
+					acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][0], acc[tq][0], 0, 0, 0);
+					continue;
+				}
 				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
 				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
 				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
