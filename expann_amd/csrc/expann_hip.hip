@@ -406,7 +406,9 @@ int f16_lds_bytes(int d) {
 	               : (d == 128 ? gemm_f16_lds_bytes<128>()
 	                           : (d == 256 ? gemm_f16_lds_bytes<256>() : gemm_f16_lds_bytes<512>()));
 }
-int f16_threads(int d) { return d >= 256 ? F16Geom<256>::THREADS : F16Geom<128>::THREADS; }
+int f16_threads(int d) {
+	return d >= 256 ? F16Geom<256>::THREADS : (d == 64 ? F16Geom<64>::THREADS : F16Geom<128>::THREADS);
+}
 int f16_wg_per_cu(int d) {
 	return d >= 256 ? F16Geom<256>::WG_PER_CU : (d == 64 ? F16Geom<64>::WG_PER_CU : F16Geom<128>::WG_PER_CU);
 }
