@@ -250,30 +250,49 @@ __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS ops are in order)
 	// exact re-score, two candidates per 16-lane group in flight; slot i is read and rewritten
 	// by the one group that owns it.  (Lists with final scores -- the 8-bit forms -- skip it.)
-	for (uint32_t i0 = 0; p.rerank_base && i0 < n_s; i0 += 8) {
-		float acc[2];
-		uint32_t row[2];
+	for (uint32_t i0 = 0; p.rerank_base && i0 < n_s; i0 += 16) {
+		constexpr int U = 4;  // candidates per 16-lane group in flight
+		float acc[U];
+		uint32_t row[U];
+		const float* r[U];
 #pragma unroll
-		for (int u = 0; u < 2; ++u) {
+		for (int u = 0; u < U; ++u) {
 			const uint32_t i = i0 + 4 * u + grp;
 			row[u] = key_idx(list[i < n_s ? i : 0]);
+			r[u] = p.rerank_base + (size_t)row[u] * p.dim + l;
+			acc[u] = 0.0f;
 		}
+		// 8 dims of every candidate are requested before any is consumed (the trip count is a
+		// run-time value: without this the loop waits for each load in turn); per candidate the
+		// FMA chain still runs over t in increasing order, as the reference's lane does
+		const uint32_t nt = p.dim / 16;
+		for (uint32_t t0 = 0; t0 < nt; t0 += 8) {
+			float qv[8], rv[U][8];
 #pragma unroll
-		for (int u = 0; u < 2; ++u) {
-			const float* r = p.rerank_base + (size_t)row[u] * p.dim + l;
-			float a = 0.0f;
-			for (uint32_t t = 0; t < p.dim / 16; ++t) {
-				if (p.metric_ip) {
-					a = __builtin_fmaf(q[16 * t], r[16 * t], a);
-				} else {
-					const float diff = q[16 * t] - r[16 * t];
-					a = __builtin_fmaf(diff, diff, a);
+			for (int t = 0; t < 8; ++t)
+				qv[t] = t0 + t < nt ? q[16 * (t0 + t)] : 0.0f;
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					rv[u][t] = t0 + t < nt ? r[u][16 * (t0 + t)] : 0.0f;
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					if (t0 + t >= nt)
+						continue;  // (d = 64: four dims per lane)
+					if (p.metric_ip) {
+						acc[u] = __builtin_fmaf(qv[t], rv[u][t], acc[u]);
+					} else {
+						const float diff = qv[t] - rv[u][t];
+						acc[u] = __builtin_fmaf(diff, diff, acc[u]);
+					}
 				}
-			}
-			acc[u] = reduce16_ref_order(a);
 		}
 #pragma unroll
-		for (int u = 0; u < 2; ++u) {
+		for (int u = 0; u < U; ++u) {
+			acc[u] = reduce16_ref_order(acc[u]);
 			const uint32_t i = i0 + 4 * u + grp;
 			if (l == 0 && i < n_s)
 				list[i] = make_key(p.metric_ip ? -acc[u] : acc[u], row[u]);
