@@ -1473,6 +1473,7 @@ restart_direct:
 			                    ? pr * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
 			                    : 0.0f;
 			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
+			sel.qnrm = (use_gemm && gvf) ? h->d_qnrm : nullptr;
 			sel.overflow = h->d_overflow;
 			if (last && sel.cand_cnt && h->profiling)  // statistics: candidates of the full scan
 				hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,

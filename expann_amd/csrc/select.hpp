@@ -37,6 +37,7 @@ struct SelectParams {
 	uint32_t* overflow;       // [1] number of queries whose list overflowed cap
 	uint32_t wave_done;       // select_wave_kernel already served the lists of <= wave_done keys
 	uint32_t wave0_short;     // select_topk_kernel: lists of <= 2048 keys go through wave 0's wave path
+	const float* qnrm;        // [m] ||q||^2 if the caller has it (pruning margin), else nullptr
 };
 
 // statistics: *out = sum of counts (one workgroup; one same-address atomic per query in the
@@ -207,9 +208,13 @@ __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint
 	float cutoff = __builtin_inff();
 	if (p.prune_eps > 0.0f && c > p.k) {
 		float qn = 0.0f;
-		for (uint32_t t = 0; t < p.dim / 16; ++t)
-			qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
-		qn = reduce16_ref_order(qn);
+		if (p.qnrm) {
+			qn = p.qnrm[qi];
+		} else {
+			for (uint32_t t = 0; t < p.dim / 16; ++t)
+				qn = __builtin_fmaf(q[16 * t], q[16 * t], qn);
+			qn = reduce16_ref_order(qn);
+		}
 		// k-th smallest approximate score (k-th DISTINCT one if scores repeat: a valid, looser cut)
 		uint32_t sc[PER];
 #pragma unroll
