@@ -565,9 +565,6 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 	return EXPANN_OK;
 }
 
-// Rows read by the sampled pass = 1/frac.  Its cost falls with frac, the candidates of the full
-// scan (~1.2 k frac per query) grow with it: the optimum moves as 1/sqrt(k); 16 at k = 10 (measured
-// flat from 12 to 16), 5 at k = 100.
 // one wave per query for lists of <= 512 keys, then (when the buffers allow longer lists) for
 // <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
 void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st) {
@@ -581,10 +578,15 @@ void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t s
 	}
 }
 
+// Rows read by the sampled pass = 1/frac.  Its cost falls with frac, the candidates of the full
+// scan (~1.2 k frac per query) grow with it.  Measured optima: 12-16 at k = 10 (flat), 8 at
+// k = 100 (3.44 ms per 2500 queries x 5 M rows against 3.65 at 5 and 3.62 at 16).
+// (8-bit forms: the scan is twice as fast, the candidates cost the same: 5 at k = 100.)
 uint32_t sample_frac_for(const expann_index* h, size_t k) {
 	if (h->opt_sample_frac > 0)
 		return (uint32_t)h->opt_sample_frac;
-	const double f = 16.0 * std::sqrt(10.0 / (double)std::max<size_t>(1, k));
+	const double expo = h->dtype == EXPANN_DTYPE_F32 ? 0.3 : 0.5;
+	const double f = 16.0 * std::pow(10.0 / (double)std::max<size_t>(1, k), expo);
 	return (uint32_t)std::min(32.0, std::max(4.0, std::round(f)));
 }
 
