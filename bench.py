@@ -35,9 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--d", type=int, default=128)
-    ap.add_argument("--m", type=int, default=10_000)
+    # (--rows / --dim / --queries: spellings that survive torch.distributed.run's own option parser,
+    # which rejects --n, --d and --m as ambiguous abbreviations of its flags)
+    ap.add_argument("--n", "--rows", type=int, default=1_000_000)
+    ap.add_argument("--d", "--dim", type=int, default=128)
+    ap.add_argument("--m", "--queries", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "i8", "u8"])
