@@ -20,6 +20,7 @@
 #include "scan_f32.hpp"
 #include "scan_gemm_bf16.hpp"
 #include "scan_gemm_f16.hpp"
+#include "scan_gemm_f16k.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_gemm_i8q.hpp"
@@ -370,7 +371,9 @@ const GemmVariant kGemmF32[] = {
 // dims that only the fp16 form covers: a placeholder without kernels (scan == nullptr) keeps the
 // GEMM branch of the level loop alive; without the fp16 form it counts as "no GEMM form"
 const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}, {512, nullptr, nullptr, nullptr, "-"},
-                                    {64, nullptr, nullptr, nullptr, "-"}, {128, nullptr, nullptr, nullptr, "-"}};
+                                    {64, nullptr, nullptr, nullptr, "-"},  {128, nullptr, nullptr, nullptr, "-"},
+                                    {768, nullptr, nullptr, nullptr, "-"}, {832, nullptr, nullptr, nullptr, "-"},
+                                    {960, nullptr, nullptr, nullptr, "-"}};
 
 using GemmBf16Fn = void (*)(GemmBf16Params);
 struct GemmBf16Variant {
@@ -391,27 +394,21 @@ struct GemmF16Variant {
 	SqnormFn sqnorm;
 	F16PrepFn prep;
 	const char* name;
+	int tb, wgq, threads, wg_per_cu, lds;  // rows per tile, queries per workgroup, launch geometry
 };
-const GemmF16Variant kGemmF16[] = {
-    {64, scan_gemm_f16_kernel<64, false>, scan_gemm_f16_kernel<64, true>, sqnorm_kernel<64>,
-     f16_query_prep_kernel<64>, "scan_gemm_f16<64, false>"},
-    {128, scan_gemm_f16_kernel<128, false>, scan_gemm_f16_kernel<128, true>, sqnorm_kernel<128>,
-     f16_query_prep_kernel<128>, "scan_gemm_f16<128, false>"},
-    {256, scan_gemm_f16_kernel<256, false>, scan_gemm_f16_kernel<256, true>, sqnorm_kernel<256>,
-     f16_query_prep_kernel<256>, "scan_gemm_f16<256, false>"},
-    {512, scan_gemm_f16_kernel<512, false>, scan_gemm_f16_kernel<512, true>, sqnorm_kernel<512>,
-     f16_query_prep_kernel<512>, "scan_gemm_f16<512, false>"}};
-int f16_lds_bytes(int d) {
-	return d == 64 ? gemm_f16_lds_bytes<64>()
-	               : (d == 128 ? gemm_f16_lds_bytes<128>()
-	                           : (d == 256 ? gemm_f16_lds_bytes<256>() : gemm_f16_lds_bytes<512>()));
-}
-int f16_threads(int d) {
-	return d >= 256 ? F16Geom<256>::THREADS : (d == 64 ? F16Geom<64>::THREADS : F16Geom<128>::THREADS);
-}
-int f16_wg_per_cu(int d) {
-	return d >= 256 ? F16Geom<256>::WG_PER_CU : (d == 64 ? F16Geom<64>::WG_PER_CU : F16Geom<128>::WG_PER_CU);
-}
+#define F16_V(D)                                                                                   \
+	{D, scan_gemm_f16_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,            \
+	 f16_query_prep_kernel<D>, "scan_gemm_f16<" #D ", false>", kF16TB, F16Geom<D>::WGQ,              \
+	 F16Geom<D>::THREADS, F16Geom<D>::WG_PER_CU, gemm_f16_lds_bytes<D>()}
+// 512 < d <= 960: the k range split over wave pairs (scan_gemm_f16k.hpp)
+#define F16K_V(D)                                                                                  \
+	{D, scan_gemm_f16k_kernel<D, false>, scan_gemm_f16k_kernel<D, true>, sqnorm_kernel<D>,          \
+	 f16_query_prep_kernel<D>, "scan_gemm_f16k<" #D ", false>", F16kGeom<D>::TB, F16kGeom<D>::WGQ,   \
+	 F16kGeom<D>::THREADS, 1, F16kGeom<D>::LDS_BYTES}
+const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(512),
+                                   F16K_V(768), F16K_V(832), F16K_V(960)};
+#undef F16_V
+#undef F16K_V
 
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
@@ -458,10 +455,10 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	const float abs_coef = std::ldexp(1.0f, -24) / scale * std::sqrt((float)h->dim);
 	const int ipm = h->metric == EXPANN_METRIC_IP ? 1 : 0;
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
-	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(), abs_coef,
+	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(h->dim), abs_coef,
 	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16, ipm);
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
-	                   0, st, (const float*)nrm.p, (uint32_t)h->n, -gemm_f16_filter_eps(), -abs_coef,
+	                   0, st, (const float*)nrm.p, (uint32_t)h->n, -gemm_f16_filter_eps(h->dim), -abs_coef,
 	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16, ipm);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
@@ -486,7 +483,9 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	// step, m = 32: 0.49 vs 0.41 ms -- below ~24 queries the HBM-bound direct scan wins.  fp16
 	// form (half the bytes per row, one sampled pass): 0.175 vs 0.175 ms at m = 4, 0.173 vs 0.199
 	// at m = 8, 0.185 vs 0.31 at m = 16 -- from 5 queries on it wins.
-	const bool f16_dims = (h->dim == 64 || h->dim == 128 || h->dim == 256 || h->dim == 512) && h->f16_scale >= 0.0f;
+	bool f16_dims = false;
+	for (const auto& v : kGemmF16Only)
+		f16_dims = f16_dims || (v.d == h->dim && h->f16_scale >= 0.0f);
 	if (h->opt_scan_kernel == 0 && (m < (f16_dims ? 5u : 24u) || h->n < 4096))
 		return nullptr;
 	for (const auto& v : kGemmF32)
@@ -1039,7 +1038,7 @@ restart_direct:
 			if (v.d == h->dim)
 				gvf = &v;
 	if (h->opt_scan_kernel == 4 && !gvf && !no_f16)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 L2 with dim 64, 128, 256 or 512 only");
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
 	if (gvf)
 		gvb = nullptr;
 	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))
@@ -1126,11 +1125,11 @@ restart_direct:
 		size_t li_start = 0;
 		bool theta_ready = false;  // the sample pass also wrote theta' and zeroed the list counters
 		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
-			const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
+			const uint32_t nt = (uint32_t)((h->n + gvf->tb - 1) / gvf->tb);
 			const uint32_t run = (uint32_t)h->opt_sample_run;
 			uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
-			const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-			uint32_t chunks = std::max<uint32_t>(1, ((uint32_t)f16_wg_per_cu(h->dim) * (uint32_t)cus) / nqt);
+			const uint32_t nqt = (uint32_t)((m + gvf->wgq - 1) / gvf->wgq);
+			uint32_t chunks = std::max<uint32_t>(1, ((uint32_t)gvf->wg_per_cu * (uint32_t)cus) / nqt);
 			chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 			chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
 			if (t_sel * 2 <= nt && (size_t)chunks * 32 >= 8 * k) {
@@ -1156,8 +1155,7 @@ restart_direct:
 				fp.m = (uint32_t)m;
 				fp.sample_out = h->d_sample;
 				fp.n_chunks = chunks;
-				hipLaunchKernelGGL(gvf->sample, dim3(chunks * nqt), dim3((uint32_t)f16_threads(h->dim)),
-				                   f16_lds_bytes(h->dim), st, fp);
+				hipLaunchKernelGGL(gvf->sample, dim3(chunks * nqt), dim3((uint32_t)gvf->threads), gvf->lds, st, fp);
 				li_start = levels.size() - 1;
 				SampleTauParams tp{};
 				tp.vals = h->d_sample;
@@ -1165,7 +1163,7 @@ restart_direct:
 				tp.m = (uint32_t)m;
 				tp.k = (uint32_t)k;
 				tp.qnrm = h->d_qnrm;
-				tp.eps = gemm_f16_filter_eps();
+				tp.eps = gemm_f16_filter_eps(h->dim);
 				tp.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
 				tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
 				tp.ip = ip ? 1 : 0;
@@ -1224,7 +1222,7 @@ restart_direct:
 				else if (gvf)
 					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
 					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
-					                   gemm_f16_filter_eps(), f16_abs, (const float*)sp.tau,
+					                   gemm_f16_filter_eps(h->dim), f16_abs, (const float*)sp.tau,
 					                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0);
 				else
 					hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
@@ -1240,7 +1238,7 @@ restart_direct:
 				gp.n_tiles_sel = last ? n_tiles
 				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
 				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				const uint32_t tq_wg = gvf ? (uint32_t)kF16TQ : (gvb ? kGemmBf16TQ : kGemmTQ);
+				const uint32_t tq_wg = gvf ? (uint32_t)gvf->wgq : (gvb ? kGemmBf16TQ : kGemmTQ);
 				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
 				gp.queries = (const float*)d_queries;
 				gp.theta = h->d_theta;
@@ -1276,8 +1274,8 @@ restart_direct:
 					fp.base_f16 = h->d_base_f16;
 					fp.bnorm = h->d_bnorm_f16;
 					fp.n_rows = gp.n_rows;
-					const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
-					fp.n_tiles_sel = last ? nt : std::min(nt, (L.n_groups_sel * kRowsPerGroup + kF16TB - 1) / kF16TB);
+					const uint32_t nt = (uint32_t)((h->n + gvf->tb - 1) / gvf->tb);
+					fp.n_tiles_sel = last ? nt : std::min(nt, (L.n_groups_sel * kRowsPerGroup + gvf->tb - 1) / gvf->tb);
 					fp.tile_stride = std::max<uint32_t>(1, nt / fp.n_tiles_sel);
 					fp.tile_run = 1;
 					if (!last && fp.tile_stride >= 16 && fp.n_tiles_sel >= 16) {
@@ -1285,10 +1283,10 @@ restart_direct:
 						fp.tile_run = 16;
 						fp.n_tiles_sel = (fp.n_tiles_sel / 16) * 16;
 					}
-					fp.n_qtiles = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
+					fp.n_qtiles = (uint32_t)((m + gvf->wgq - 1) / gvf->wgq);
 					uint32_t fchunks = 1;
 					{
-						const uint32_t slots = (uint32_t)f16_wg_per_cu(h->dim) * (uint32_t)cus;
+						const uint32_t slots = (uint32_t)gvf->wg_per_cu * (uint32_t)cus;
 						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
 						double best = 1e300;
 						double best8 = 1e300;
@@ -1330,16 +1328,13 @@ restart_direct:
 						HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
 						fp.clk = clk.as<unsigned long long>();
 					}
-					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)f16_threads(h->dim)),
-					                   f16_lds_bytes(h->dim),
+					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
 					                   st, fp);
 					kname = gvf->name;
 					gp.n_qtiles = fp.n_qtiles;
 					if (fp.clk) {
 						int occ = -1;
-						hipOccupancyMaxActiveBlocksPerMultiprocessor(
-						    &occ, (const void*)gvf->scan, f16_threads(h->dim),
-						    f16_lds_bytes(h->dim));
+						hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gvf->scan, gvf->threads, gvf->lds);
 						std::fprintf(stderr, "scan_gemm_f16: %d workgroups per CU resident, grid %u\n", occ,
 						             fchunks * fp.n_qtiles);
 						unsigned long long c[18] = {0};
@@ -1468,7 +1463,7 @@ restart_direct:
 			// (inner product, fp16 form only: the approximate key is off by at most E_q + E_b in
 			// total, half the L2 margins)
 			const float pr = ip ? 1.0f : 2.0f;
-			sel.prune_eps = use_gemm ? (gvf ? pr * gemm_f16_filter_eps()
+			sel.prune_eps = use_gemm ? (gvf ? pr * gemm_f16_filter_eps(h->dim)
 			                                : (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)))
 			                         : 0.0f;
 			sel.prune_abs = (use_gemm && gvf)
@@ -1631,11 +1626,9 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	}
 	for (const auto& v : kGemmF16)
 		if (v.d == dim)
-			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        f16_lds_bytes(dim)) !=
+			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) !=
 			        hipSuccess ||
-			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        f16_lds_bytes(dim)) !=
+			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) !=
 			        hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
 				hipStreamDestroy(h->stream);

@@ -9,7 +9,8 @@
 // <= tau_q when evaluated with the slack
 //      1.125 * 2^-10 * (||q||^2 + ||b||^2)  +  2^-24/s * sqrt(d) * (|q| + |b|)
 // (the 12.5 % on top of 2^-10 covers the fp32 accumulation, the norms and the reference-order
-// rounding, (4d+226) * 2^-24 at most).  The slack admits ~10 % more candidates than the exact
+// rounding, (4.25 d + 256) * 2^-24 at most, up to d = 256; beyond, gemm_f16_filter_eps(d) grows
+// with d).  The slack admits ~10 % more candidates than the exact
 // test; they are re-scored exactly by the select kernel, so ids and distances stay bit-identical
 // to the direct scan.  Queries whose scaled components would leave the fp16 range make the
 // engine use the bf16x3 form for that search.
@@ -37,7 +38,15 @@ namespace expann {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__host__ __device__ inline float gemm_f16_filter_eps() { return 1.125f * 0.0009765625f; }
+// relative slack of the filter on (||q||^2 + ||b||^2).  Beyond the input rounding (2^-10 + 2^-22)
+// it has to cover, in units of u = 2^-24: d roundings of the fp32 accumulation at any association,
+// each on a running magnitude <= |theta'| + sum|q16 b16| <= 4 (||q||^2 + ||b||^2) mul  (4d), the
+// reference-order score (d/8 + 14), the two norms (d/16 + 5 each) and the threshold terms (~20):
+// <= 4.25 d + 256.  Up to d = 256 the flat 12.5 % (2048 u) is at least that.
+__host__ __device__ inline float gemm_f16_filter_eps(int d) {
+	return d <= 256 ? 1.125f * 0.0009765625f
+	                : 0.0009765625f + (4.0f + 4.25f * (float)d + 256.0f) * 5.9604644775390625e-08f;
+}
 
 // fp32 [n_values] * scale -> fp16 (round to nearest even); *maxabs_bits (optional, zeroed by the
 // caller) receives the bit pattern of max |in| -- for non-negative floats the unsigned integer
