@@ -21,6 +21,7 @@
 #include "scan_gemm_bf16.hpp"
 #include "scan_gemm_f16.hpp"
 #include "scan_gemm_f16k.hpp"
+#include "scan_direct_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_gemm_i8q.hpp"
@@ -84,6 +85,11 @@ struct expann_index {
 	uint32_t* d_overflow = nullptr;  // [4]: overflow count
 	unsigned long long* d_total = nullptr;
 	uint32_t* h_flags = nullptr;     // pinned [4]
+	// latency mode (expann_search with few queries): pinned staging [queries | ids | dists]; the
+	// select kernels store the results straight into it, so a search costs one async H2D copy of
+	// the queries, the kernels, and the flag read-back -- one host sync, no pageable copies
+	void* h_pin = nullptr;
+	size_t h_pin_bytes = 0;
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
 	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
@@ -119,6 +125,7 @@ struct expann_index {
 	size_t io_q_bytes = 0, io_out = 0;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
+	long opt_latency_mode = 1;  // few queries from host buffers: results land in pinned memory
 	long opt_debug = 0;
 	long opt_sample_frac = 0;        // the sampled pass reads 1/frac of the rows; 0 = by k (sample_frac_for)
 	long opt_sample_run = 1;         // consecutive 64-row tiles per sampled stretch.  1: the sample
@@ -410,6 +417,31 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 #undef F16_V
 #undef F16K_V
 
+// a handful of queries: the same filter streamed from HBM without the matrix cores
+// (scan_direct_f16.hpp); tq = queries per pass
+struct DirectF16Variant {
+	int d, tq, rps;
+	GemmF16Fn fn;
+	const char* name;
+};
+#define DF16_V(D, TQ) {D, TQ, DirectF16Geom<D>::RPS, scan_direct_f16_kernel<D, TQ>, "scan_direct_f16<" #D ", " #TQ ">"}
+const DirectF16Variant kDirectF16[] = {DF16_V(64, 2),  DF16_V(64, 4),  DF16_V(128, 2), DF16_V(128, 4),
+                                       DF16_V(256, 2), DF16_V(256, 4), DF16_V(512, 1), DF16_V(512, 2),
+                                       DF16_V(768, 1), DF16_V(832, 1), DF16_V(960, 1)};
+#undef DF16_V
+// the variant for m queries: ONE pass (measured at 1M x d128: a second pass, or 8 queries per
+// pass -- VALU-bound --, loses to the MFMA form), else the other paths take over
+const DirectF16Variant* pick_direct_f16(int d, size_t m) {
+	const DirectF16Variant* best = nullptr;
+	for (const auto& v : kDirectF16) {
+		if (v.d != d)
+			continue;
+		if (!best || ((size_t)best->tq < m && v.tq > best->tq) || ((size_t)v.tq >= m && v.tq < best->tq))
+			best = &v;
+	}
+	return (best && m <= (size_t)best->tq) ? best : nullptr;
+}
+
 // fp16 copy of the base (scaled by a power of two), its slack-adjusted norms, max norm
 int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	if (h->d_base_f16 || h->f16_scale < 0.0f)
@@ -472,7 +504,7 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	if (h->metric == EXPANN_METRIC_IP) {
 		// inner product: only the fp16 form has it (a placeholder variant keeps the GEMM branch alive)
 		const bool ok = (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4) && h->f16_scale >= 0.0f &&
-		                !(h->opt_scan_kernel == 0 && (m < 5 || h->n < 4096));
+		                !(h->opt_scan_kernel == 0 && ((m < 5 && !pick_direct_f16(h->dim, m)) || h->n < 4096));
 		if (ok)
 			for (const auto& v : kGemmF16Only)
 				if (v.d == h->dim)
@@ -486,7 +518,8 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	bool f16_dims = false;
 	for (const auto& v : kGemmF16Only)
 		f16_dims = f16_dims || (v.d == h->dim && h->f16_scale >= 0.0f);
-	if (h->opt_scan_kernel == 0 && (m < (f16_dims ? 5u : 24u) || h->n < 4096))
+	if (h->opt_scan_kernel == 0 &&
+	    ((m < (f16_dims ? 5u : 24u) && !(f16_dims && pick_direct_f16(h->dim, m))) || h->n < 4096))
 		return nullptr;
 	for (const auto& v : kGemmF32)
 		if (v.d == h->dim)
@@ -1239,6 +1272,7 @@ restart_direct:
 				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
 				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
 				const uint32_t tq_wg = gvf ? (uint32_t)gvf->wgq : (gvb ? kGemmBf16TQ : kGemmTQ);
+				uint32_t tq_small = 0;
 				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
 				gp.queries = (const float*)d_queries;
 				gp.theta = h->d_theta;
@@ -1328,9 +1362,25 @@ restart_direct:
 						HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
 						fp.clk = clk.as<unsigned long long>();
 					}
-					hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
-					                   st, fp);
-					kname = gvf->name;
+					const DirectF16Variant* dv =
+					    (last && h->opt_scan_kernel == 0) ? pick_direct_f16(h->dim, m) : nullptr;
+					if (dv) {
+						// a handful of queries: stream the fp16 rows without the matrix cores, ~16
+						// workgroups per CU, whole RPS-row steps (inside the copy's 64-row padding)
+						fp.n_qtiles = (uint32_t)((m + dv->tq - 1) / dv->tq);
+						fp.n_tiles_sel = (uint32_t)((h->n + dv->rps - 1) / dv->rps);
+						const uint32_t want = std::max<uint32_t>(1, (16u * (uint32_t)cus) / fp.n_qtiles);
+						fp.tiles_per_block = std::max<uint32_t>(8, (fp.n_tiles_sel + want - 1) / want);
+						fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
+						fp.xcd_map = 0;
+						hipLaunchKernelGGL(dv->fn, dim3(fchunks * fp.n_qtiles), dim3(kBlock), 0, st, fp);
+						kname = dv->name;
+						tq_small = (uint32_t)dv->tq;
+					} else {
+						hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
+						                   st, fp);
+						kname = gvf->name;
+					}
 					gp.n_qtiles = fp.n_qtiles;
 					if (fp.clk) {
 						int occ = -1;
@@ -1378,7 +1428,7 @@ restart_direct:
 					kname = gv->name;
 				}
 				passes = gp.n_qtiles;
-				qt_used = tq_wg;
+				qt_used = tq_small ? tq_small : tq_wg;
 			} else if (gvi && !first) {
 				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 				                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,
@@ -1707,6 +1757,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_qself) hipFree(h->d_qself);
 	if (h->d_theta) hipFree(h->d_theta);
 	if (h->h_flags) hipHostFree(h->h_flags);
+	if (h->h_pin) hipHostFree(h->h_pin);
 	if (h->d_q) hipFree(h->d_q);
 	if (h->d_q8) hipFree(h->d_q8);
 	if (h->d_ids) hipFree(h->d_ids);
@@ -1857,6 +1908,31 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 		h->io_q_bytes = 0;
 		HIP_TRY(h, hipMalloc(&h->d_q, qbytes));
 		h->io_q_bytes = qbytes;
+	}
+	if (m * k <= 16384 && qbytes <= (256u << 10) && m <= kMaxQueriesPerPass && h->opt_latency_mode) {
+		const size_t ids_off = (qbytes + 63) / 64 * 64;
+		const size_t dists_off = ids_off + sizeof(uint64_t) * m * k;
+		const size_t need = dists_off + sizeof(float) * m * k;
+		if (need > h->h_pin_bytes) {
+			if (h->h_pin) hipHostFree(h->h_pin);
+			h->h_pin = nullptr;
+			h->h_pin_bytes = 0;
+			const size_t want = std::max<size_t>(need, 64u << 10);
+			HIP_TRY(h, hipHostMalloc(&h->h_pin, want, hipHostMallocDefault));
+			h->h_pin_bytes = want;
+		}
+		char* pin = (char*)h->h_pin;
+		std::memcpy(pin, queries, qbytes);
+		HIP_TRY(h, hipMemcpyAsync(h->d_q, pin, qbytes, hipMemcpyHostToDevice, h->stream));
+		// (search_pass ends with the flag read-back and a stream sync: the results are complete)
+		int rc = expann_search_device(h, h->d_q, m, k, (uint64_t*)(pin + ids_off), (float*)(pin + dists_off),
+		                              h->stream);
+		if (rc != EXPANN_OK)
+			return rc;
+		std::memcpy(ids, pin + ids_off, sizeof(uint64_t) * m * k);
+		if (dists)
+			std::memcpy(dists, pin + dists_off, sizeof(float) * m * k);
+		return EXPANN_OK;
 	}
 	if (m * k > h->io_out) {
 		if (h->d_ids) hipFree(h->d_ids);
@@ -2023,7 +2099,7 @@ struct GraphVariant {
 	GraphFn fn;
 };
 #define GRAPH_V(D) {D, false, graph_search_kernel<D, false>}, {D, true, graph_search_kernel<D, true>}
-const GraphVariant kGraph[] = {GRAPH_V(64), GRAPH_V(128), GRAPH_V(256)};
+const GraphVariant kGraph[] = {GRAPH_V(64), GRAPH_V(128), GRAPH_V(256), GRAPH_V(832), GRAPH_V(960)};
 #undef GRAPH_V
 }  // namespace
 
@@ -2046,7 +2122,7 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 	for (const auto& v : kGraph)
 		dim_ok |= v.d == dim;
 	if (!dim_ok) {
-		g_create_error = "graph search is built for dim 64, 128, 256";
+		g_create_error = "graph search is built for dim 64, 128, 256, 832, 960";
 		return EXPANN_ERR_UNSUPPORTED;
 	}
 	const uint64_t n_edges = layer_offsets[(size_t)n_layers * (n + 1) - 1];
@@ -2465,6 +2541,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))
 		h->opt_u8_exact = value;
+	else if (!std::strcmp(name, "latency_mode"))
+		h->opt_latency_mode = value;
 	else if (!std::strcmp(name, "sample_run"))
 		h->opt_sample_run = value < 1 ? 1 : (value > 64 ? 64 : value);
 	else if (!std::strcmp(name, "sample_frac"))

@@ -200,7 +200,10 @@ int expann_get_profile(expann_index* h, expann_profile* out);
  * "sample_frac" (the sampled pass reads 1/frac of the rows; 0 = chosen from k (default)),
  * "u8_exact" (1 (default): an fp32 L2 index of dim 128 / 256 whose values are all integers in
  * [0, 255] keeps a uint8 copy, and batches of 8-bit integer queries are searched through the
- * exact 8-bit kernels -- same ids and fp32 distances; 0: never). */
+ * exact 8-bit kernels -- same ids and fp32 distances; 0: never),
+ * "latency_mode" (1 (default): expann_search with few queries (m*k <= 16384) stages them in
+ * pinned memory and lets the select kernels store the results there -- one host sync per
+ * search and no pageable copies; 0: always the plain copy path). */
 int expann_set_option(expann_index* h, const char* name, long value);
 
 #ifdef __cplusplus

@@ -46,7 +46,7 @@ def test_builder_index_format_roundtrip_and_graph_quality(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("data,d", [("sift", 128), ("gauss", 64)])
+@pytest.mark.parametrize("data,d", [("sift", 128), ("gauss", 64), ("sift", 960), ("sift", 832)])
 def test_gpu_traversal_matches_oracle(tmp_path, oracle, data, d):
     idx, qf, rf = tmp_path / "g.index", tmp_path / "g.queries", tmp_path / "g.results"
     n, m, k = 1500, 64, 10
