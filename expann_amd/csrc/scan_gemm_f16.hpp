@@ -667,12 +667,15 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
 	uint64_t kth = 0;
+	__shared__ uint32_t scratch[kBlock / 64][64];
 	if (p.k > 24 || PER >= 16) {  // bisection on the value: 32 steps whatever k and list length
 		uint32_t ord[PER];
 #pragma unroll
 		for (int j = 0; j < PER; ++j)
 			ord[j] = (uint32_t)(keys[j] >> 32);
-		kth = (uint64_t)wave_kth_largest_u32<PER>(ord, p.k) << 32;
+		kth = (uint64_t)(p.k <= 64 ? wave_kth_largest_sparse_u32<PER>(ord, p.k, scratch[threadIdx.x >> 6], lane)
+		                           : wave_kth_largest_u32<PER>(ord, p.k))
+		      << 32;
 	} else
 	for (uint32_t it = 0; it < p.k; ++it) {
 		uint64_t best = 0;

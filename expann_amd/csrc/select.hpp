@@ -194,6 +194,41 @@ template <int PER> __device__ inline uint32_t wave_kth_largest_u32(const uint32_
 	return lo;
 }
 
+// The same k-th largest when k <= 64 and PER is large: B = the k-th largest of the 64 per-lane
+// maxima is a lower bound of the answer (k values >= B exist) and usually only a few more values
+// reach it -- they are compacted into `scratch` (64 words of LDS, this wave's own) and the
+// bisection runs over one value per lane instead of PER.  Falls back to the full bisection when
+// more than 64 values reach B (ties, k close to the number of values).
+template <int PER>
+__device__ inline uint32_t wave_kth_largest_sparse_u32(const uint32_t (&v)[PER], uint32_t k, uint32_t* scratch,
+                                                       int lane) {
+	uint32_t mx[1] = {v[0]};
+#pragma unroll
+	for (int j = 1; j < PER; ++j)
+		mx[0] = v[j] > mx[0] ? v[j] : mx[0];
+	const uint32_t B = wave_kth_largest_u32<1>(mx, k);
+	uint32_t total = 0;
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		total += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[j] >= B));
+	if (total > 64)
+		return wave_kth_largest_u32<PER>(v, k);
+	uint32_t base = 0;  // wave-uniform
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const unsigned long long mask = __builtin_amdgcn_ballot_w64(v[j] >= B);
+		if (v[j] >= B)
+			scratch[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+			                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = v[j];
+		base += (uint32_t)__builtin_popcountll(mask);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint32_t w[1] = {lane < (int)total ? scratch[lane] : 0u};
+	return wave_kth_largest_u32<1>(w, k);
+}
+
 // one wave orders the list of query qi (c <= 64 * PER keys); list = 64 * PER keys of LDS
 template <int PER>
 __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint32_t c, uint64_t* list,
