@@ -228,7 +228,8 @@ struct ScanI8Variant {
 	"scan_filter_i16<" #DE "," #TQ ",L2REF>"}
 const ScanI8Variant kScanI8[] = {SCAN_I8(64, 1),  SCAN_I8(64, 16), SCAN_I8(128, 1), SCAN_I8(128, 4),
                                  SCAN_I8(128, 16), SCAN_I8(256, 1), SCAN_I8(256, 8), SCAN_I8(768, 1),
-                                 SCAN_I8(768, 4),  SCAN_I8(768, 8), SCAN_I8(960, 1), SCAN_I8(960, 4),
+                                 SCAN_I8(768, 4),  SCAN_I8(768, 8), SCAN_I8(832, 1), SCAN_I8(832, 4),
+                                 SCAN_I8(960, 1),  SCAN_I8(960, 4),
                                  SCAN_I16(64, 1),  SCAN_I16(64, 4), SCAN_I16(64, 16), SCAN_I16(128, 1),
                                  SCAN_I16(128, 8)};
 #undef SCAN_I16
@@ -265,7 +266,7 @@ struct ScoreI8Variant {
 };
 #define SCORE_I8(D) {D, kU8L2, score_ids_i8_kernel<D, kU8L2>}, {D, kI8L2, score_ids_i8_kernel<D, kI8L2>}, \
 	{D, kI8L2Ref, score_ids_i8_kernel<D, kI8L2Ref>}, {D, kI8IP, score_ids_i8_kernel<D, kI8IP>}
-const ScoreI8Variant kScoreI8[] = {SCORE_I8(64), SCORE_I8(128), SCORE_I8(256), SCORE_I8(768), SCORE_I8(960),
+const ScoreI8Variant kScoreI8[] = {SCORE_I8(64), SCORE_I8(128), SCORE_I8(256), SCORE_I8(768), SCORE_I8(832), SCORE_I8(960),
                                    {64, kI16L2Ref, score_ids_i8_kernel<128, kI16L2Ref>},
                                    {128, kI16L2Ref, score_ids_i8_kernel<256, kI16L2Ref>}};
 #undef SCORE_I8
@@ -630,22 +631,23 @@ struct GemmI8qVariant {
 	SelfI8Fn self;
 	ThetaI8Fn theta;
 	const char* name;
+	int dq;  // physical row bytes of the engine's copy (> d: zero-padded, scan_gemm_i8q.hpp)
+	int lds, threads, wg_per_cu;
 };
-#define GEMM_I8Q(D, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<D, L2F, false>, \
-	scan_gemm_i8q_kernel<D, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
-	"scan_gemm_i8q<" #D "," MN ">"}
+#define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false>, \
+	scan_gemm_i8q_kernel<DQ, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+	"scan_gemm_i8q<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
+#define GEMM_I8Q(D, MODE, L2F, MN) GEMM_I8Q_P(D, D, MODE, L2F, MN)
 const GemmI8qVariant kGemmI8q[] = {
     GEMM_I8Q(128, kU8L2, true, "U8L2"), GEMM_I8Q(128, kI8L2, true, "I8L2"), GEMM_I8Q(128, kI8IP, false, "I8IP"),
     GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP"),
-    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP")};
+    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP"),
+    GEMM_I8Q_P(832, 1024, kU8L2, true, "U8L2"), GEMM_I8Q_P(832, 1024, kI8L2, true, "I8L2"),
+    GEMM_I8Q_P(832, 1024, kI8IP, false, "I8IP"),
+    GEMM_I8Q_P(960, 1024, kU8L2, true, "U8L2"), GEMM_I8Q_P(960, 1024, kI8L2, true, "I8L2"),
+    GEMM_I8Q_P(960, 1024, kI8IP, false, "I8IP")};
 #undef GEMM_I8Q
-int i8q_lds_bytes(int d) {
-	return d == 128 ? gemm_i8q_lds_bytes<128>() : (d == 256 ? gemm_i8q_lds_bytes<256>() : gemm_i8q_lds_bytes<768>());
-}
-int i8q_threads(int d) { return d == 768 ? I8qGeom<768>::THREADS : I8qGeom<128>::THREADS; }
-int i8q_wg_per_cu(int d) {
-	return d == 768 ? I8qGeom<768>::WG_PER_CU : (d == 256 ? I8qGeom<256>::WG_PER_CU : I8qGeom<128>::WG_PER_CU);
-}
+#undef GEMM_I8Q_P
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
 constexpr int kStrictReject = -1001;  // internal (uint8 shadow): these queries are not 8-bit integers
 
@@ -675,7 +677,16 @@ int ensure_i8q(expann_index* h, const GemmI8qVariant* gq, hipStream_t st) {
 	hipLaunchKernelGGL(i8q_bp_kernel, dim3((uint32_t)((n_pad + kBlock - 1) / kBlock)), dim3(kBlock), 0,
 	                   st, h->int_mode != kI8IP ? (const int*)h->d_bias_i : (const int*)nullptr,
 	                   (uint32_t)h->n, (uint32_t)n_pad, h->d_bp_i8q);
-	if (h->int_mode == kU8L2 || n_pad != h->n) {
+	if (gq->dq != h->dim) {
+		// own copy with rows padded to dq bytes (zeros in the int8 domain), whole 64-row tiles
+		void* copy = nullptr;
+		HIP_TRY(h, hipMalloc(&copy, n_pad * (size_t)gq->dq));
+		hipLaunchKernelGGL(i8q_pad_rows_kernel, dim3(8192), dim3(kBlock), 0, st, (const uint32_t*)h->d_base, h->n,
+		                   (uint32_t)h->dim / 4, (uint32_t)gq->dq / 4, n_pad,
+		                   h->int_mode == kU8L2 ? 0x80808080u : 0u, (uint32_t*)copy);
+		h->d_base_i8q = copy;
+		h->base_i8q_owned = true;
+	} else if (h->int_mode == kU8L2 || n_pad != h->n) {
 		// own copy: whole 64-row tiles (zero rows behind the end), uint8 rows mapped to int8
 		void* copy = nullptr;
 		HIP_TRY(h, hipMalloc(&copy, n_pad * h->dim));
@@ -709,7 +720,21 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	if (rc != EXPANN_OK)
 		return rc;
 	const void* q8 = d_queries;
-	if (h->int_mode == kU8L2) {  // queries ^ 0x80 (d_queries is the uint8 conversion, d_q8)
+	if (gq->dq != h->dim) {  // rows of the padded geometry: queries padded (and mapped) the same way
+		const size_t nb = m * (size_t)gq->dq;
+		if (nb > h->q_split_bytes) {
+			if (h->d_q_split) hipFree(h->d_q_split);
+			h->d_q_split = nullptr;
+			h->q_split_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_q_split, nb));
+			h->q_split_bytes = nb;
+		}
+		hipLaunchKernelGGL(i8q_pad_rows_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
+		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, m, (uint32_t)h->dim / 4,
+		                   (uint32_t)gq->dq / 4, m, h->int_mode == kU8L2 ? 0x80808080u : 0u,
+		                   (uint32_t*)h->d_q_split);
+		q8 = h->d_q_split;
+	} else if (h->int_mode == kU8L2) {  // queries ^ 0x80 (d_queries is the uint8 conversion, d_q8)
 		const size_t nb = m * (size_t)h->dim;
 		if (nb > h->q_split_bytes) {
 			if (h->d_q_split) hipFree(h->d_q_split);
@@ -727,14 +752,14 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	const uint32_t run = (uint32_t)h->opt_sample_run;
 	const uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 	const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-	const uint32_t wg_slots = (uint32_t)i8q_wg_per_cu(h->dim) * (uint32_t)cus;
+	const uint32_t wg_slots = (uint32_t)gq->wg_per_cu * (uint32_t)cus;
 	uint32_t chunks = std::max<uint32_t>(1, wg_slots / nqt);
 	chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 	chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
 	if (t_sel * 2 > nt || (size_t)chunks * 32 < 8 * k)
 		return kRetryGeneric;
-	const int lds = i8q_lds_bytes(h->dim);
-	const dim3 wg((uint32_t)i8q_threads(h->dim));
+	const int lds = gq->lds;
+	const dim3 wg((uint32_t)gq->threads);
 	for (int attempt = 0;; ++attempt) {
 		rc = ensure_workspace(h, m, cap);
 		if (rc != EXPANN_OK)
@@ -1649,7 +1674,7 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	if ((int_mode < 0 && !pick_scan_f32(dim, metric == EXPANN_METRIC_IP, 1, 0)) ||
 	    (int_mode >= 0 && !pick_scan_i8(dim, int_mode, 1, 0))) {
 		g_create_error = "unsupported dim " + std::to_string(dim) +
-		                 " (built: f32 64,128,256,512,768,832,960,1024; 8-bit 64,128,256,768,960)";
+		                 " (built: f32 64,128,256,512,768,832,960,1024; 8-bit 64,128,256,768,832,960)";
 		return EXPANN_ERR_UNSUPPORTED;
 	}
 	expann_index* h = new expann_index();
@@ -1688,9 +1713,9 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	for (const auto& v : kGemmI8q)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        i8q_lds_bytes(dim)) != hipSuccess ||
+			                        v.lds) != hipSuccess ||
 			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        i8q_lds_bytes(dim)) != hipSuccess) {
+			                        v.lds) != hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_i8q_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
@@ -1804,6 +1829,15 @@ int expann_build(expann_index* h) {
 	HIP_TRY(h, hipMemcpy(h->d_base, h->staging.data(), h->staging.size(), hipMemcpyHostToDevice));
 	h->n = h->n_staged;
 	std::vector<unsigned char>().swap(h->staging);
+	// the fp16 copy every fp32 search of a built dim filters through: made here, inside the
+	// reference's timed build span (basic_bench.h:63-71), not inside the first query
+	if (h->dtype == EXPANN_DTYPE_F32 && h->n >= 4096 && h->opt_scan_kernel == 0)
+		for (const auto& v : kGemmF16)
+			if (v.d == h->dim) {
+				const int rc = ensure_f16(h, &v, h->stream);
+				if (rc != EXPANN_OK)
+					return rc;
+			}
 	return EXPANN_OK;
 }
 

@@ -62,6 +62,19 @@ __global__ __launch_bounds__(kBlock) void i8q_copy_xor_kernel(const uint32_t* in
 		out[i] = i < n_words ? in[i] ^ x : 0u;
 }
 
+// rows of d bytes -> rows of dq >= d bytes: out[r][c] = in[r][c] ^ x for r < n_rows, c < d; else 0
+// (4 bytes at a time; d, dq multiples of 4)
+__global__ __launch_bounds__(kBlock) void i8q_pad_rows_kernel(const uint32_t* in, size_t n_rows, uint32_t dw,
+                                                              uint32_t dqw, size_t n_rows_pad, uint32_t x,
+                                                              uint32_t* out) {
+	const size_t total = n_rows_pad * dqw;
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+		const size_t r = i / dqw;
+		const uint32_t c = (uint32_t)(i - r * dqw);
+		out[i] = (r < n_rows && c < dw) ? in[r * dw + c] ^ x : 0u;
+	}
+}
+
 __device__ inline int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 // Geometry by dimension.  d = 128 / 256: as scan_gemm_f16.hpp (4 waves x 64 queries, two
@@ -70,18 +83,21 @@ __device__ inline int max3i(int a, int b, int c) { return max(max(a, b), c); }
 // halving the queries per tile would double the L2->LDS traffic that bounds this shape), 2 tile
 // buffers of 48 KB, and the 16-byte chunks of a row are assigned to (k-step, lane half) in
 // natural order (2s + h), which needs 8 fragment-address registers instead of 24.
+// d = 1024 is the PHYSICAL row length of d = 832 / 960 indexes: their 832- / 960-byte rows (64 /
+// 192 mod 256) have no conflict-free XOR swizzle, so the engine's padded copy stores them in
+// 1024 bytes (zeros in the mapped int8 domain add nothing to q.b); two 64 KB tile buffers.
 template <int D> struct I8qGeom {
-	static constexpr int THREADS = D == 768 ? 512 : 256;
+	static constexpr int THREADS = D >= 768 ? 512 : 256;
 	static constexpr int WAVES = THREADS / 64;
-	static constexpr int TQW = D == 768 ? 1 : 2;      // 32-query MFMA tiles per wave
+	static constexpr int TQW = D >= 768 ? 1 : 2;      // 32-query MFMA tiles per wave
 	static constexpr int WGQ = WAVES * 32 * TQW;      // queries per workgroup
-	static constexpr int NBUF = D == 768 ? 2 : 3;
+	static constexpr int NBUF = D >= 768 ? 2 : 3;
 	// d = 128: the query fragments are only 32 VGPRs; with the accumulator start values read from
 	// LDS at every step instead of held in 32 more, the scan fits 168 VGPRs and THREE workgroups
 	// share a CU (3 waves per SIMD to cover each other's barriers and flushes)
 	static constexpr bool TH_LDS = D == 128;
-	static constexpr int QCAP = D == 768 ? 56 : (TH_LDS ? 56 : 88);  // queue entries per wave
-	static constexpr bool NATURAL = D == 768;
+	static constexpr int QCAP = D == 1024 ? 24 : (D == 768 ? 56 : (TH_LDS ? 56 : 88));  // queue entries per wave
+	static constexpr bool NATURAL = D >= 768;
 	static constexpr int WG_PER_CU = TH_LDS ? 3 : 512 / THREADS;
 };
 static_assert(I8qGeom<128>::WGQ == kF16TQ && I8qGeom<768>::WGQ == kF16TQ, "one query-tile size");
@@ -91,14 +107,15 @@ template <int D> constexpr int gemm_i8q_lds_bytes() {
 	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16 +
 	       (G::TH_LDS ? G::WAVES * 2 * G::TQW * 16 * 4 : 0);
 }
-static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<256>() * 2 <= 160 * 1024 &&
+static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<1024>() <= 160 * 1024 &&
+                  gemm_i8q_lds_bytes<256>() * 2 <= 160 * 1024 &&
                   gemm_i8q_lds_bytes<128>() * 3 <= 160 * 1024,
               "LDS budget per CU");
 
 template <int D, bool L2FORM, bool SAMPLE>
 __global__ __launch_bounds__(I8qGeom<D>::THREADS, (I8qGeom<D>::TH_LDS && !SAMPLE) ? 3 : 2) void
 scan_gemm_i8q_kernel(GemmI8qParams p) {
-	static_assert(D == 128 || D == 256 || D == 768, "built for d = 128, 256, 768");
+	static_assert(D == 128 || D == 256 || D == 768 || D == 1024, "built for d = 128, 256, 768, 1024");
 	using G = I8qGeom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
 	constexpr bool NATURAL = G::NATURAL;

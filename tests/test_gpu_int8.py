@@ -61,7 +61,8 @@ def test_u8_rejects_queries_outside_8_bits(oracle):
 
 @pytest.mark.parametrize("metric,ometric", [("l2", "METRIC_L2_I8"), ("ip", "METRIC_IP_I8"),
                                             ("l2_i8_refcompat", "METRIC_L2_I8_REFCOMPAT")])
-@pytest.mark.parametrize("n,d,m,k", [(6000, 128, 19, 10), (3000, 768, 9, 10), (30000, 64, 5, 10)])
+@pytest.mark.parametrize("n,d,m,k", [(6000, 128, 19, 10), (3000, 768, 9, 10), (30000, 64, 5, 10),
+                                     (5000, 832, 6, 10), (5000, 960, 3, 10)])
 def test_int8_metrics(oracle, metric, ometric, n, d, m, k):
     rng = np.random.RandomState(n * 3 + d)
     base = rng.randint(-127, 128, size=(n, d)).astype(np.int8)
@@ -140,6 +141,9 @@ def test_gemm_form_int8_mfma(oracle, dtype, metric, ometric, d, n, m, k):
     ("i8", "l2", "METRIC_L2_I8", 128), ("i8", "ip", "METRIC_IP_I8", 128),
     ("i8", "l2", "METRIC_L2_I8", 256), ("i8", "ip", "METRIC_IP_I8", 256),
     ("i8", "ip", "METRIC_IP_I8", 768), ("i8", "l2", "METRIC_L2_I8", 768), ("u8", "l2", "METRIC_L2_U8", 768),
+    # d = 832 / 960 (the reference's other builds): rows padded to 1024 bytes in the engine's copy
+    ("u8", "l2", "METRIC_L2_U8", 832), ("i8", "ip", "METRIC_IP_I8", 832), ("i8", "l2", "METRIC_L2_I8", 960),
+    ("u8", "l2", "METRIC_L2_U8", 960), ("i8", "ip", "METRIC_IP_I8", 960),
 ])
 @pytest.mark.parametrize("n,m,k", [(40000, 130, 10), (70001, 300, 17), (65536, 97, 100)])
 def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
