@@ -384,6 +384,14 @@ def main():
             tops = ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS,
                         "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
+        elif prof["scan_kernel"].startswith("scan_direct_f16"):
+            # a handful of queries: the fp16 filter streamed from HBM (scan_direct_f16.hpp) reads the
+            # scaled fp16 copy (2 B per element) + one 4-byte row term per row and pass
+            gbs = passes * n_local * (a.d * 2 + 4) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "note": "bytes = passes x N x (2 d + 4): the fp16 rows the filter reads; "
+                                "hbm_view prices the same time against the fp32 rows (SURVEY 8d: N*d*4)"}
         elif prof["scan_kernel"].startswith("scan_gemm_f16"):
             # one fp16 MFMA product per fp32 product (scaled operands, rigorous slack, exact
             # re-rank): executed flops = algorithmic 2*N*d*m, priced against the dense fp16 peak

@@ -13,4 +13,12 @@ run --n 1000000 --d 64 --k 10 --steps 10
 run --n 1000000 --dtype u8 --steps 10
 run --n 1000000 --dtype i8 --metric ip --steps 10
 run --n 1000000 --d 256 --dtype i8 --steps 10
+run --n 1000000 --d 768 --steps 3
+run --n 1000000 --d 832 --steps 3
+run --n 1000000 --d 960 --steps 3
+run --n 1000000 --d 960 --metric ip --steps 3
+run --n 1000000 --d 960 --dtype u8 --steps 3
+run --n 1000000 --d 832 --dtype u8 --steps 3
+run --n 1000000 --k 10 --m 1 --steps 50
+run --n 1000000 --k 10 --m 4 --steps 50
 run --workload c5 --steps 3

@@ -104,8 +104,12 @@ def main():
             known = 1_000_000 * 128 * 4
             cal = known / (e["FETCH_SIZE_KiB_avg_full_grid"] * 1024)
             e["known_bytes_per_launch"] = known
+        if "scan_direct_f16" in k and "FETCH_SIZE_KiB_avg_full_grid" in e:
+            known = 1_000_000 * (128 * 2 + 4)      # the fp16 rows + one fp32 row term each
+            cal = known / (e["FETCH_SIZE_KiB_avg_full_grid"] * 1024)
+            e["known_bytes_per_launch"] = known
     summary["fetch_size_calibration"] = {
-        "factor": cal, "basis": "m=1 scan: one pass over N*d*4 = 512e6 B, base > Infinity Cache",
+        "factor": cal, "basis": "m=1 scan: one pass over the rows it streams (fp32: N*d*4 = 512e6 B; fp16 filter: N*(2d+4) = 260e6 B), larger than the Infinity Cache",
         "guide": "MI355X_MICROARCH.md HBM: FETCH_SIZE = half of streamed bytes on gfx950"}
     for run, r in summary["runs"].items():
         for k, e in r["kernels"].items():
