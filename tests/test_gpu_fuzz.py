@@ -34,10 +34,10 @@ def test_random_configuration_matches_the_oracle(oracle, seed):
     from expann_amd import GpuBruteForceEngine
     rng = np.random.RandomState(1000 + seed)
     dtype = rng.choice(["f32", "f32", "f32", "u8", "i8"])
-    d = int(rng.choice([64, 128, 128, 256, 512, 832, 960] if dtype == "f32" else [128, 256]))
+    d = int(rng.choice([64, 128, 128, 256, 512, 832, 960] if dtype == "f32" else [128, 128, 256, 768, 832, 960]))
     n = int(rng.choice([700, 5000, 20000, 40000, 70001, 131072]))
     m = int(rng.choice([1, 3, 5, 8, 23, 64, 97, 130, 300]))
-    k = int(rng.choice([1, 5, 10, 10, 17, 64]))
+    k = int(rng.choice([1, 5, 10, 10, 17, 64, 100]))
     metric = "l2"
     if dtype == "f32":
         metric = str(rng.choice(["l2", "l2", "ip"]))
