@@ -623,7 +623,7 @@ uint32_t sample_frac_for(const expann_index* h, size_t k) {
 	return (uint32_t)std::min(32.0, std::max(4.0, std::round(f)));
 }
 
-// ---- 8-bit GEMM form, queue geometry (scan_gemm_i8q.hpp), d = 128 / 256 ----------------------
+// ---- 8-bit GEMM form, queue geometry (scan_gemm_i8q.hpp), d = 128 / 256 / 768 / 832 / 960 -----
 using GemmI8qFn = void (*)(GemmI8qParams);
 struct GemmI8qVariant {
 	int d, mode;
@@ -1075,7 +1075,7 @@ restart_direct:
 	const GemmI8Variant* gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
 	if (h->opt_scan_kernel == 2 && !gv && !gvi)
 		return h->fail(EXPANN_ERR_UNSUPPORTED,
-		               "GEMM-form scan: f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
+		               "GEMM-form scan (scan_kernel=2): f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
 	if (gvi) {
 		int rc = ensure_bias_i8(h, gvi, st);
 		if (rc != EXPANN_OK)

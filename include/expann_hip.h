@@ -194,7 +194,7 @@ int expann_get_profile(expann_index* h, expann_profile* out);
  * "scan_kernel" (0 = auto, 1 = direct VALU scan, 2 = GEMM form on the fp32 / int8 matrix
  * cores, 3 = GEMM form on the bf16 matrix cores with the 3-term split, 4 = GEMM form with one
  * scaled fp16 product, 5 = 8-bit rows: int8 MFMA form with per-wave hit queues (d = 128,
- * 256); the final ids and distances are identical for every choice),
+ * 256, 768, 832, 960); the final ids and distances are identical for every choice),
  * "sample_ratio" (rows ratio between the levels of the threshold ladder, default 32),
  * "sample_pass" (fp16 form: 1 = one sampled pass gives the threshold (default), 0 = ladder),
  * "sample_frac" (the sampled pass reads 1/frac of the rows; 0 = chosen from k (default)),
