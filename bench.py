@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-ratio", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--xcd-tolerance", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--scan-chunks", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sample-run", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sift-like", action="store_true",
                     help="f32 rows and queries hold integers 0..255 (SURVEY 8d's SIFT stand-in)")
@@ -285,6 +287,10 @@ def main():
         eng.set_option("sample_ratio", a.sample_ratio)
     if a.sample_frac:
         eng.set_option("sample_frac", a.sample_frac)
+    if a.scan_chunks:
+        eng.set_option("scan_chunks", a.scan_chunks)
+    if a.xcd_tolerance >= 0:
+        eng.set_option("xcd_tolerance", a.xcd_tolerance)
     if a.sample_run:
         eng.set_option("sample_run", a.sample_run)
     from expann_amd.sharded import GridShardedSearch, chunk_bytes, unpack_chunk

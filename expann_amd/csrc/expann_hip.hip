@@ -89,6 +89,7 @@ struct expann_index {
 	// select kernels store the results straight into it, so a search costs one async H2D copy of
 	// the queries, the kernels, and the flag read-back -- one host sync, no pageable copies
 	void* h_pin = nullptr;
+	uint32_t* d_ticket = nullptr;  // last-workgroup counter of sample_direct_f16_kernel (0 between launches)
 	size_t h_pin_bytes = 0;
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
 	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
@@ -125,6 +126,8 @@ struct expann_index {
 	size_t io_q_bytes = 0, io_out = 0;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
+	long opt_scan_chunks = 0;
+	long opt_xcd_tolerance = 3;  // % of modelled cost given up for an XCD-aligned chunk count
 	long opt_latency_mode = 1;  // few queries from host buffers: results land in pinned memory
 	long opt_debug = 0;
 	long opt_sample_frac = 0;        // the sampled pass reads 1/frac of the rows; 0 = by k (sample_frac_for)
@@ -358,6 +361,9 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
 		h->d_total = reinterpret_cast<unsigned long long*>(h->d_overflow + 4);
 		HIP_TRY(h, hipHostMalloc((void**)&h->h_flags, sizeof(uint32_t) * 8, 0));
+		HIP_TRY(h, hipMalloc(&h->d_ticket, sizeof(uint32_t)));
+		HIP_TRY(h, hipMemset(h->d_ticket, 0, sizeof(uint32_t)));
+		HIP_TRY(h, hipDeviceSynchronize());  // (once per handle: the counter is zero before any stream uses it)
 	}
 	return EXPANN_OK;
 }
@@ -420,16 +426,23 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 
 // a handful of queries: the same filter streamed from HBM without the matrix cores
 // (scan_direct_f16.hpp); tq = queries per pass
+using SampleDirectFn = void (*)(SampleDirectParams);
 struct DirectF16Variant {
 	int d, tq, rps;
 	GemmF16Fn fn;
 	const char* name;
+	SampleDirectFn sample;  // fused sampled pass + thresholds (nullptr: the MFMA SAMPLE pass serves)
+	int cpw;                // its classes per workgroup
 };
-#define DF16_V(D, TQ) {D, TQ, DirectF16Geom<D>::RPS, scan_direct_f16_kernel<D, TQ>, "scan_direct_f16<" #D ", " #TQ ">"}
+#define DF16_V(D, TQ) {D, TQ, DirectF16Geom<D>::RPS, scan_direct_f16_kernel<D, TQ>, "scan_direct_f16<" #D ", " #TQ ">", \
+	sample_direct_f16_kernel<D, TQ>, DirectF16Geom<D>::RW * (kBlock / 64)}
+#define DF16_VN(D, TQ) {D, TQ, DirectF16Geom<D>::RPS, scan_direct_f16_kernel<D, TQ>, "scan_direct_f16<" #D ", " #TQ ">", \
+	nullptr, 0}
 const DirectF16Variant kDirectF16[] = {DF16_V(64, 2),  DF16_V(64, 4),  DF16_V(128, 2), DF16_V(128, 4),
                                        DF16_V(256, 2), DF16_V(256, 4), DF16_V(512, 1), DF16_V(512, 2),
-                                       DF16_V(768, 1), DF16_V(832, 1), DF16_V(960, 1)};
+                                       DF16_VN(768, 1), DF16_VN(832, 1), DF16_VN(960, 1)};
 #undef DF16_V
+#undef DF16_VN
 // the variant for m queries: ONE pass (measured at 1M x d128: a second pass, or 8 queries per
 // pass -- VALU-bound --, loses to the MFMA form), else the other paths take over
 const DirectF16Variant* pick_direct_f16(int d, size_t m) {
@@ -842,7 +855,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 					g8 = g;
 				}
 			}
-			if (g8 && best8 <= best * 1.03 && !(h->opt_debug & 1024)) {
+			if (g8 && best8 <= best * (1.0 + 0.01 * (double)h->opt_xcd_tolerance) && !(h->opt_debug & 1024)) {
 				fchunks = g8;
 				fp.xcd_map = 1;
 			}
@@ -1182,7 +1195,56 @@ restart_direct:
 		// intermediate candidate lists and selects
 		size_t li_start = 0;
 		bool theta_ready = false;  // the sample pass also wrote theta' and zeroed the list counters
-		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
+		const DirectF16Variant* dvs =
+		    (gvf && h->opt_sample_pass && levels.size() >= 2 && h->opt_scan_kernel == 0) ? pick_direct_f16(h->dim, m)
+		                                                                              : nullptr;
+		if (dvs && dvs->sample) {
+			// a handful of queries: sampled pass and thresholds in ONE launch (scan_direct_f16.hpp)
+			const uint32_t steps_all = (uint32_t)((h->n + dvs->rps - 1) / dvs->rps);
+			const uint32_t sel = std::max<uint32_t>(256u * 64u / (uint32_t)dvs->rps,
+			                                        steps_all / sample_frac_for(h, k));
+			uint32_t wgs = std::min<uint32_t>(2048u / (uint32_t)dvs->cpw, sel / 4);
+			if (sel * 2 <= steps_all && (size_t)wgs * dvs->cpw >= 8 * k) {
+				SampleDirectParams sp{};
+				sp.g.base_f16 = h->d_base_f16;
+				sp.g.bnorm = h->d_bns_f16;
+				sp.g.n_rows = (uint32_t)h->n;
+				sp.g.n_tiles_sel = sel;
+				sp.g.tile_stride = steps_all / sel;
+				sp.g.tiles_per_block = (sel + wgs - 1) / wgs;
+				wgs = (sel + sp.g.tiles_per_block - 1) / sp.g.tiles_per_block;
+				sp.g.queries_f16 = h->d_q_split;
+				sp.g.m = (uint32_t)m;
+				const size_t need = m * (size_t)wgs * dvs->cpw * sizeof(float);
+				if (need > h->sample_bytes) {
+					if (h->d_sample) hipFree(h->d_sample);
+					h->d_sample = nullptr;
+					h->sample_bytes = 0;
+					HIP_TRY(h, hipMalloc(&h->d_sample, need));
+					h->sample_bytes = need;
+				}
+				li_start = levels.size() - 1;
+				sp.t.vals = h->d_sample;
+				sp.t.n_vals = wgs * (uint32_t)dvs->cpw;
+				sp.t.m = (uint32_t)m;
+				sp.t.k = (uint32_t)k;
+				sp.t.qnrm = h->d_qnrm;
+				sp.t.eps = gemm_f16_filter_eps(h->dim);
+				sp.t.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
+				sp.t.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
+				sp.t.ip = ip ? 1 : 0;
+				sp.t.tau = h->d_tau[(li_start + 1) & 1];
+				sp.t.tau_row = h->d_tau_row[(li_start + 1) & 1];
+				sp.t.theta = h->d_theta;
+				sp.t.mul = 0.5f * h->f16_scale * h->f16_scale;
+				sp.t.cand_cnt = h->d_cnt;
+				sp.ticket = h->d_ticket;
+				theta_ready = true;
+				hipLaunchKernelGGL(dvs->sample, dim3(wgs), dim3(kBlock), 0, st, sp);
+				HIP_TRY(h, hipGetLastError());
+			}
+		}
+		if (gvf && h->opt_sample_pass && levels.size() >= 2 && !theta_ready) {
 			const uint32_t nt = (uint32_t)((h->n + gvf->tb - 1) / gvf->tb);
 			const uint32_t run = (uint32_t)h->opt_sample_run;
 			uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
@@ -1366,10 +1428,17 @@ restart_direct:
 								g8 = g;
 							}
 						}
-						if (g8 && best8 <= best * 1.03 && !(h->opt_debug & 1024)) {
+						if (g8 && best8 <= best * (1.0 + 0.01 * (double)h->opt_xcd_tolerance) && !(h->opt_debug & 1024)) {
 							fchunks = g8;
 							fp.xcd_map = 1;
 						}
+					}
+					if (h->opt_scan_chunks > 0) {  // (experiments: force the row-chunk count)
+						fchunks = (uint32_t)std::min<long>(h->opt_scan_chunks, std::max<uint32_t>(1, fp.n_tiles_sel / 8));
+						fp.xcd_map = (fchunks % 8 == 0 && !(h->opt_debug & 1024)) ? 1 : 0;
+						const uint32_t tpb = (fp.n_tiles_sel + fchunks - 1) / fchunks;
+						if ((fp.n_tiles_sel + tpb - 1) / tpb != fchunks)
+							fp.xcd_map = 0;
 					}
 					fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;
 					fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
@@ -1783,6 +1852,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_theta) hipFree(h->d_theta);
 	if (h->h_flags) hipHostFree(h->h_flags);
 	if (h->h_pin) hipHostFree(h->h_pin);
+	if (h->d_ticket) hipFree(h->d_ticket);
 	if (h->d_q) hipFree(h->d_q);
 	if (h->d_q8) hipFree(h->d_q8);
 	if (h->d_ids) hipFree(h->d_ids);
@@ -2577,6 +2647,10 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_u8_exact = value;
 	else if (!std::strcmp(name, "latency_mode"))
 		h->opt_latency_mode = value;
+	else if (!std::strcmp(name, "scan_chunks"))
+		h->opt_scan_chunks = value;
+	else if (!std::strcmp(name, "xcd_tolerance"))
+		h->opt_xcd_tolerance = value < 0 ? 0 : value;
 	else if (!std::strcmp(name, "sample_run"))
 		h->opt_sample_run = value < 1 ? 1 : (value > 64 ? 64 : value);
 	else if (!std::strcmp(name, "sample_frac"))

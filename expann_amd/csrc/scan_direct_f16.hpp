@@ -154,4 +154,123 @@ __global__ __launch_bounds__(kBlock) void scan_direct_f16_kernel(GemmF16Params p
 			process(buf[i], g + i);
 }
 
+// The sampled pass + threshold of the handful-of-queries path in ONE launch: every workgroup
+// streams its share of the sample (RPS-row steps spread evenly over the index), each (wave, row
+// group) keeps the maximum of g = q16.b16 - bns over its rows -- one class per lane group, so the
+// k largest class maxima belong to k different rows, as in the MFMA SAMPLE pass -- and the LAST
+// workgroup to finish (ticket counter, agent-scope fences) turns the class maxima into tau /
+// theta' and zeroes the list counters, one wave per query (sample_tau_query).
+struct SampleDirectParams {
+	GemmF16Params g;    // base_f16, bnorm = UPPER row terms, queries_f16, m; n_tiles_sel = steps of the
+	                    // sample, tile_stride = step stride, tiles_per_block = steps per workgroup
+	SampleTauParams t;  // vals = class maxima [m][n_vals], n_vals = gridDim.x * classes per workgroup
+	uint32_t* ticket;   // 0 on entry; the last workgroup resets it
+};
+template <int D, int TQ>
+__global__ __launch_bounds__(kBlock) void sample_direct_f16_kernel(SampleDirectParams p) {
+	using G = DirectF16Geom<D>;
+	constexpr int LPR = G::LPR, CPL = G::CPL, RW = G::RW, RPS = G::RPS, NB = G::NB;
+	constexpr int CPW = RW * (kBlock / 64);  // classes per workgroup
+	static_assert(TQ <= kBlock / 64, "one wave per query in the threshold step");
+	__shared__ uint32_t scratch[kBlock / 64][64];
+	__shared__ uint32_t s_ticket;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int l = lane % LPR, rg = lane / LPR;
+	const uint32_t chunk = blockIdx.x;
+
+	f32x2 q2[TQ][CPL][4];
+#pragma unroll
+	for (int j = 0; j < TQ; ++j) {
+		const uint32_t qi = (uint32_t)j < p.g.m ? j : p.g.m - 1;
+		const f16x8* src = reinterpret_cast<const f16x8*>((const _Float16*)p.g.queries_f16 + (size_t)qi * D) + l;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const f16x8 v = src[LPR * c];
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+				q2[j][c][e] = f32x2{(float)v[2 * e], (float)v[2 * e + 1]};
+		}
+	}
+	const uint32_t g0 = chunk * p.g.tiles_per_block;
+	uint32_t g1 = g0 + p.g.tiles_per_block;
+	if (g1 > p.g.n_tiles_sel)
+		g1 = p.g.n_tiles_sel;
+	auto row_of = [&](uint32_t g) -> uint32_t { return g * p.g.tile_stride * RPS + wave * RW + rg; };
+	struct RowBuf {
+		f16x8 r[CPL];
+		float bn;
+	};
+	auto load_row = [&](RowBuf& b, uint32_t g) {
+		const uint32_t row = row_of(g);
+		const f16x8* src = reinterpret_cast<const f16x8*>((const _Float16*)p.g.base_f16 + (size_t)row * D) + l;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c)
+			b.r[c] = src[LPR * c];
+		b.bn = p.g.bnorm[row];
+	};
+	float best[TQ];
+#pragma unroll
+	for (int j = 0; j < TQ; ++j)
+		best[j] = -__builtin_inff();
+	auto process = [&](const RowBuf& b) {
+		f32x2 acc[TQ];
+#pragma unroll
+		for (int j = 0; j < TQ; ++j)
+			acc[j] = f32x2{0.0f, 0.0f};
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			f32x2 rf[4];
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+				rf[e] = f32x2{(float)b.r[c][2 * e], (float)b.r[c][2 * e + 1]};
+#pragma unroll
+			for (int j = 0; j < TQ; ++j)
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+					acc[j] = pk_fma(q2[j][c][e], rf[e], acc[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < TQ; ++j)  // a NaN bns (padding row) never wins the max
+			best[j] = __builtin_fmaxf(best[j], reduce_lanes<LPR>(acc[j][0] + acc[j][1]) - b.bn);
+	};
+	RowBuf buf[NB];
+#pragma unroll
+	for (int i = 0; i < NB; ++i)
+		if (g0 + i < g1)
+			load_row(buf[i], g0 + i);
+	uint32_t g = g0;
+	for (; g + NB <= g1; g += NB) {
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			process(buf[i]);
+			if (g + NB + i < g1)
+				load_row(buf[i], g + NB + i);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < NB; ++i)
+		if (g + i < g1)
+			process(buf[i]);
+	if (l == 0) {
+#pragma unroll
+		for (int j = 0; j < TQ; ++j)
+			if ((uint32_t)j < p.g.m)
+				const_cast<float*>(p.t.vals)[(size_t)j * p.t.n_vals + chunk * CPW + wave * RW + rg] = best[j];
+	}
+	// last workgroup: thresholds (the class maxima of the others are visible after the fences)
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0)
+		s_ticket = atomicAdd(p.ticket, 1u);
+	__syncthreads();
+	if (s_ticket != gridDim.x - 1)
+		return;
+	__threadfence();
+	if ((uint32_t)wave < p.g.m)
+		sample_tau_query<32>(p.t, (uint32_t)wave, lane, scratch[wave]);
+	if (threadIdx.x == 0)
+		*p.ticket = 0;
+}
+
 }  // namespace expann

@@ -652,12 +652,9 @@ struct SampleTauParams {
 	float mul;
 	uint32_t* cand_cnt;  // [m] <- 0 (the full scan's list counters)
 };
+// the work of one wave for query qi; scratch = 64 words of LDS of this wave's own
 template <int PER>  // values per lane: n_vals <= 64 * PER
-__global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
-	const int lane = threadIdx.x & 63;
-	const uint32_t qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	if (qi >= p.m)
-		return;  // (whole wave)
+__device__ inline void sample_tau_query(const SampleTauParams& p, uint32_t qi, int lane, uint32_t* scratch) {
 	const float* v = p.vals + (size_t)qi * p.n_vals;
 	uint64_t keys[PER];
 #pragma unroll
@@ -667,13 +664,12 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
 	uint64_t kth = 0;
-	__shared__ uint32_t scratch[kBlock / 64][64];
 	if (p.k > 24 || PER >= 16) {  // bisection on the value: 32 steps whatever k and list length
 		uint32_t ord[PER];
 #pragma unroll
 		for (int j = 0; j < PER; ++j)
 			ord[j] = (uint32_t)(keys[j] >> 32);
-		kth = (uint64_t)(p.k <= 64 ? wave_kth_largest_sparse_u32<PER>(ord, p.k, scratch[threadIdx.x >> 6], lane)
+		kth = (uint64_t)(p.k <= 64 ? wave_kth_largest_sparse_u32<PER>(ord, p.k, scratch, lane)
 		                           : wave_kth_largest_u32<PER>(ord, p.k))
 		      << 32;
 	} else
@@ -710,6 +706,14 @@ __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
 		                   : (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
 		p.cand_cnt[qi] = 0;
 	}
+}
+template <int PER>
+__global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
+	__shared__ uint32_t scratch[kBlock / 64][64];
+	const uint32_t qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (qi >= p.m)
+		return;  // (whole wave)
+	sample_tau_query<PER>(p, qi, threadIdx.x & 63, scratch[threadIdx.x >> 6]);
 }
 
 }  // namespace expann
