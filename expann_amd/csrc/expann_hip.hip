@@ -1240,8 +1240,20 @@ restart_direct:
 				sp.t.cand_cnt = h->d_cnt;
 				sp.ticket = h->d_ticket;
 				theta_ready = true;
+				DevBuf sclk;
+				if (h->opt_debug & 16) {
+					HIP_TRY(h, sclk.alloc(3 * 8));
+					sp.g.clk = sclk.as<unsigned long long>();
+				}
 				hipLaunchKernelGGL(dvs->sample, dim3(wgs), dim3(kBlock), 0, st, sp);
 				HIP_TRY(h, hipGetLastError());
+				if (sp.g.clk) {
+					unsigned long long c[3] = {0, 0, 0};
+					HIP_TRY(h, hipStreamSynchronize(st));
+					HIP_TRY(h, hipMemcpy(c, sp.g.clk, sizeof(c), hipMemcpyDeviceToHost));
+					std::fprintf(stderr, "sample_direct_f16: %u workgroups, stream %.2f us, thresholds %.2f us\n", wgs,
+					             (double)(c[1] - c[0]) / 100.0, (double)(c[2] - c[1]) / 100.0);
+				}
 			}
 		}
 		if (gvf && h->opt_sample_pass && levels.size() >= 2 && !theta_ready) {

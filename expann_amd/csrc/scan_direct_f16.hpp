@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void scan_direct_f16_kernel(GemmF16Params p
 // group) keeps the maximum of g = q16.b16 - bns over its rows -- one class per lane group, so the
 // k largest class maxima belong to k different rows, as in the MFMA SAMPLE pass -- and the LAST
 // workgroup to finish (ticket counter, agent-scope fences) turns the class maxima into tau /
-// theta' and zeroes the list counters, one wave per query (sample_tau_query).
+// theta' and zeroes the list counters (sample_tau_query_wg: radix select by the whole workgroup).
 struct SampleDirectParams {
 	GemmF16Params g;    // base_f16, bnorm = UPPER row terms, queries_f16, m; n_tiles_sel = steps of the
 	                    // sample, tile_stride = step stride, tiles_per_block = steps per workgroup
@@ -169,15 +169,20 @@ struct SampleDirectParams {
 template <int D, int TQ>
 __global__ __launch_bounds__(kBlock) void sample_direct_f16_kernel(SampleDirectParams p) {
 	using G = DirectF16Geom<D>;
-	constexpr int LPR = G::LPR, CPL = G::CPL, RW = G::RW, RPS = G::RPS, NB = G::NB;
+	constexpr int LPR = G::LPR, CPL = G::CPL, RW = G::RW, RPS = G::RPS;
+	// only ~128 workgroups run (one class per lane group, <= 2048 classes), so each wave keeps many
+	// steps in flight: 16 KB per wave at d <= 128
+	constexpr int NB = CPL >= 4 ? 4 : 16 / CPL;
 	constexpr int CPW = RW * (kBlock / 64);  // classes per workgroup
 	static_assert(TQ <= kBlock / 64, "one wave per query in the threshold step");
 	__shared__ uint32_t scratch[kBlock / 64][64];
-	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_ticket[2];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int l = lane % LPR, rg = lane / LPR;
 	const uint32_t chunk = blockIdx.x;
+	if (p.g.clk && threadIdx.x == 0 && blockIdx.x == 0)
+		p.g.clk[0] = wall_clock64();  // (debug: 100 MHz ticks at the first workgroup's start)
 
 	f32x2 q2[TQ][CPL][4];
 #pragma unroll
@@ -262,13 +267,21 @@ __global__ __launch_bounds__(kBlock) void sample_direct_f16_kernel(SampleDirectP
 	__threadfence();
 	__syncthreads();
 	if (threadIdx.x == 0)
-		s_ticket = atomicAdd(p.ticket, 1u);
+		s_ticket[0] = atomicAdd(p.ticket, 1u);
 	__syncthreads();
-	if (s_ticket != gridDim.x - 1)
+	if (s_ticket[0] != gridDim.x - 1)
 		return;
 	__threadfence();
-	if ((uint32_t)wave < p.g.m)
+	if (p.g.clk && threadIdx.x == 0)
+		p.g.clk[1] = wall_clock64();
+	if (p.g.m <= 2) {  // the whole workgroup per query (a lone wave's selection costs ~15 us)
+		for (uint32_t qi = 0; qi < p.g.m; ++qi)
+			sample_tau_query_wg(p.t, qi, &scratch[0][0], s_ticket);
+	} else if ((uint32_t)wave < p.g.m) {  // one wave per query, side by side
 		sample_tau_query<32>(p.t, (uint32_t)wave, lane, scratch[wave]);
+	}
+	if (p.g.clk && threadIdx.x == 0)
+		p.g.clk[2] = wall_clock64();
 	if (threadIdx.x == 0)
 		*p.ticket = 0;
 }

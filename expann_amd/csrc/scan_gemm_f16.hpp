@@ -652,6 +652,78 @@ struct SampleTauParams {
 	float mul;
 	uint32_t* cand_cnt;  // [m] <- 0 (the full scan's list counters)
 };
+// one thread: ord = ordered bits of the k-th largest g (0: fewer than k values) -> tau, theta', counter
+__device__ inline void sample_tau_finish(const SampleTauParams& p, uint32_t qi, uint32_t ord) {
+	float tau = __builtin_inff();
+	const float qn = p.qnrm[qi];
+	if (ord != 0) {
+		const float g = ordered_to_float(ord);
+		if (p.ip)
+			tau = 0.5f * (qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) - g * (0.5f * p.inv_mul);
+		else
+			tau = qn * (1.0f + p.eps) + p.abs_coef * __builtin_sqrtf(qn) - g * p.inv_mul;
+		if (!(tau == tau))
+			tau = __builtin_inff();
+	}
+	p.tau[qi] = tau;
+	p.tau_row[qi] = 0xFFFFFFFFu;
+	p.theta[qi] = p.ip ? (2.0f * tau + qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) * p.mul
+	                   : (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
+	p.cand_cnt[qi] = 0;
+}
+// The same threshold by a whole 256-thread workgroup (n_vals <= 2048): radix select on the ordered
+// bits, 8 bits per pass -- histogram in LDS, suffix sums by an 8-step scan, the thread whose bin
+// holds the k-th largest fixes the digit.  A lone wave issues one instruction per >= 4 cycles, so
+// the one-wave selection costs ~15 us when nothing else runs (the last workgroup of
+// sample_direct_f16_kernel); this is ~2 us.  hist / ctl: 256 + 2 words of LDS.
+__device__ inline void sample_tau_query_wg(const SampleTauParams& p, uint32_t qi, uint32_t* hist, uint32_t* ctl) {
+	const uint32_t tid = threadIdx.x;
+	const float* v = p.vals + (size_t)qi * p.n_vals;
+	uint32_t ord[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t i = j * kBlock + tid;
+		ord[j] = i < p.n_vals ? float_to_ordered(v[i]) : 0u;
+	}
+	uint32_t prefix = 0, mask = 0, krem = p.k;
+	for (int pass = 3; pass >= 0; --pass) {
+		const int sh = 8 * pass;
+		__syncthreads();  // (the previous pass's readers are done with hist / ctl)
+		hist[tid] = 0;
+		if (tid == 0)
+			ctl[0] = 0xFFFFFFFFu;
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+			if ((ord[j] & mask) == prefix)
+				atomicAdd(&hist[(ord[j] >> sh) & 255u], 1u);
+		__syncthreads();
+		const uint32_t mine = hist[tid];
+		// inclusive suffix sums: hist[t] <- sum of bins >= t
+		for (int off = 1; off < 256; off <<= 1) {
+			const uint32_t add = tid + off < 256 ? hist[tid + off] : 0u;
+			__syncthreads();
+			hist[tid] += add;
+			__syncthreads();
+		}
+		const uint32_t above = hist[tid] - mine;  // values with a larger digit
+		if (mine != 0 && above < krem && krem <= above + mine) {
+			ctl[0] = tid;
+			ctl[1] = krem - above;
+		}
+		__syncthreads();
+		const uint32_t digit = ctl[0];
+		if (digit == 0xFFFFFFFFu) {  // fewer than k values left: no threshold
+			prefix = 0;
+			break;
+		}
+		krem = ctl[1];
+		prefix |= digit << sh;
+		mask |= 0xFFu << sh;
+	}
+	if (tid == 0)
+		sample_tau_finish(p, qi, prefix);
+}
 // the work of one wave for query qi; scratch = 64 words of LDS of this wave's own
 template <int PER>  // values per lane: n_vals <= 64 * PER
 __device__ inline void sample_tau_query(const SampleTauParams& p, uint32_t qi, int lane, uint32_t* scratch) {
@@ -687,25 +759,8 @@ __device__ inline void sample_tau_query(const SampleTauParams& p, uint32_t qi, i
 		for (int j = 0; j < PER; ++j)
 			keys[j] = keys[j] == best ? 0ull : keys[j];
 	}
-	if (lane == 0) {
-		float tau = __builtin_inff();
-		if (kth != 0) {
-			const float g = ordered_to_float((uint32_t)(kth >> 32));
-			const float qn = p.qnrm[qi];
-			if (p.ip)
-				tau = 0.5f * (qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) - g * (0.5f * p.inv_mul);
-			else
-				tau = qn * (1.0f + p.eps) + p.abs_coef * __builtin_sqrtf(qn) - g * p.inv_mul;
-			if (!(tau == tau))
-				tau = __builtin_inff();
-		}
-		p.tau[qi] = tau;
-		p.tau_row[qi] = 0xFFFFFFFFu;
-		const float qn = p.qnrm[qi];
-		p.theta[qi] = p.ip ? (2.0f * tau + qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) * p.mul
-		                   : (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
-		p.cand_cnt[qi] = 0;
-	}
+	if (lane == 0)
+		sample_tau_finish(p, qi, (uint32_t)(kth >> 32));
 }
 template <int PER>
 __global__ __launch_bounds__(kBlock) void sample_tau_kernel(SampleTauParams p) {
