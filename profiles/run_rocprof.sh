@@ -3,7 +3,8 @@
 # Writes raw output under gpurun_out/prof_<tag>/ (scratch); profiles/summarize.py turns it
 # into the small per-round summaries that are committed under profiles/.
 # Separate passes: (1) --kernel-trace --stats of the default bench (C2), (2) the same for the
-# single-query pass (m=1: one pass over the base, HBM-bound), (3)+(4) PMC FETCH_SIZE passes.
+# single-query pass (m=1: one pass over the base, HBM-bound), the d = 960 k-split kernel,
+# (3)+(4) PMC FETCH_SIZE passes.
 set -e
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -13,6 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2_trace" -- python3 $B --steps 20 --warmup 3 > "$OUT/c2_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/m1_trace" -- python3 $B --steps 50 --warmup 2 --m 1 > "$OUT/m1_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/d960_trace" -- python3 $B --steps 5 --warmup 1 --rows 1000000 --dim 960 > "$OUT/d960_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/c2_fetch" -- python3 $B --steps 2 --warmup 1 > "$OUT/c2_fetch.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/m1_fetch" -- python3 $B --steps 5 --warmup 1 --m 1 > "$OUT/m1_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/c2_write" -- python3 $B --steps 2 --warmup 1 > "$OUT/c2_write.log" 2>&1
