@@ -16,6 +16,7 @@
 // meet in a 4-step DPP add.  Per dword: one v_dot4 (u8 or i8).  For the L2 forms the expanded
 // identity  sum(a-b)^2 = sum a^2 + sum b^2 - 2 sum ab  is exact in integers.
 #pragma once
+// (non-template kernels are `static`: this header is included by more than one translation unit)
 #include "common.hpp"
 #include "scan_f32.hpp"
 
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void scan_filter_i8_kernel(ScanParams p) {
 // outside [0,255] cannot be represented in the 8-bit kernels: *bad counts them.  *frac (optional)
 // counts in-range values with a fractional part (the exact-uint8 shortcut of fp32 indexes needs
 // integer queries; the uint8 engine itself truncates like the reference).
-__global__ __launch_bounds__(kBlock) void u8_query_prep_kernel(const float* q, size_t n_values,
+static __global__ __launch_bounds__(kBlock) void u8_query_prep_kernel(const float* q, size_t n_values,
                                                                uint8_t* out, uint32_t* bad,
                                                                uint32_t* frac) {
 	const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void u8_query_prep_kernel(const float* q, s
 }
 
 // count of values that are not integers in [0, 255] (grid-stride; one atomic per workgroup at most)
-__global__ __launch_bounds__(kBlock) void count_non_u8_kernel(const float* x, size_t n, uint32_t* bad) {
+static __global__ __launch_bounds__(kBlock) void count_non_u8_kernel(const float* x, size_t n, uint32_t* bad) {
 	uint32_t c = 0;
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
 		const float v = x[i];
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void count_non_u8_kernel(const float* x, si
 		atomicAdd(bad, c);
 }
 // fp32 (known to hold integers in [0, 255]) -> uint8
-__global__ __launch_bounds__(kBlock) void cast_f32_u8_kernel(const float* x, size_t n, uint8_t* out) {
+static __global__ __launch_bounds__(kBlock) void cast_f32_u8_kernel(const float* x, size_t n, uint8_t* out) {
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
 		out[i] = (uint8_t)(uint32_t)x[i];
 }
