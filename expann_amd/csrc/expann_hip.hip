@@ -606,6 +606,39 @@ void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t s
 	}
 }
 
+// Row-chunk count of a tiled scan.  `slots` workgroups are resident at a time, so a launch of
+// g chunks x n_qtiles workgroups runs in rounds: minimise rounds x (steps per workgroup +
+// `overhead` steps of prologue / tail).  With xcd != nullptr a multiple of 8 whose rounding leaves
+// exactly g chunks is preferred when it costs at most tol_pct % more: blocks b and b+8 share an
+// XCD, so the kernels can then keep a row chunk's query tiles on ONE L2 (GemmF16Params::xcd_map).
+uint32_t pick_row_chunks(uint32_t n_tiles, uint32_t n_qtiles, uint32_t slots, double overhead, uint32_t min_tiles,
+                         uint32_t g_limit, long tol_pct, uint32_t* xcd) {
+	const uint32_t gmax = std::max<uint32_t>(1, n_tiles / min_tiles);
+	uint32_t chunks = 1, g8 = 0;
+	double best = 1e300, best8 = 1e300;
+	for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, g_limit); ++g) {
+		const uint32_t steps = (n_tiles + g - 1) / g;
+		const uint64_t rounds = ((uint64_t)g * n_qtiles + slots - 1) / slots;
+		const double cost = (double)rounds * (steps + overhead);
+		if (cost < best * 0.999) {
+			best = cost;
+			chunks = g;
+		}
+		if (xcd && g % 8 == 0 && cost < best8 * 0.999 && (n_tiles + steps - 1) / steps == g) {
+			best8 = cost;
+			g8 = g;
+		}
+	}
+	if (xcd) {
+		*xcd = 0;
+		if (g8 && best8 <= best * (1.0 + 0.01 * (double)tol_pct)) {
+			chunks = g8;
+			*xcd = 1;
+		}
+	}
+	return chunks;
+}
+
 // Rows read by the sampled pass = 1/frac.  Its cost falls with frac, the candidates of the full
 // scan (~1.2 k frac per query) grow with it.  Measured optima: 12-16 at k = 10 (flat), 8 at
 // k = 100 (3.44 ms per 2500 queries x 5 M rows against 3.65 at 5 and 3.62 at 16).
@@ -817,31 +850,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		fp.cand_cnt = h->d_cnt;
 		fp.cand = h->d_cand;
 		fp.cap = cap;
-		uint32_t fchunks = 1;
-		{
-			const uint32_t slots = wg_slots;
-			const uint32_t gmax = std::max<uint32_t>(1, nt / 8);
-			double best = 1e300;
-			double best8 = 1e300;
-			uint32_t g8 = 0;
-			for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
-				const uint32_t steps = (nt + g - 1) / g;
-				const uint64_t rounds = ((uint64_t)g * nqt + slots - 1) / slots;
-				const double cost = (double)rounds * (steps + 4.0);
-				if (cost < best * 0.999) {
-					best = cost;
-					fchunks = g;
-				}
-				if (g % 8 == 0 && cost < best8 * 0.999 && (nt + steps - 1) / steps == g) {
-					best8 = cost;
-					g8 = g;
-				}
-			}
-			if (g8 && best8 <= best * (1.0 + 0.01 * (double)h->opt_xcd_tolerance) && !(h->opt_debug & 1024)) {
-				fchunks = g8;
-				fp.xcd_map = 1;
-			}
-		}
+		uint32_t fchunks = pick_row_chunks(nt, nqt, wg_slots, 4.0, 8, 2048, h->opt_xcd_tolerance,
+		                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
 		fp.tiles_per_block = (nt + fchunks - 1) / fchunks;
 		fchunks = (nt + fp.tiles_per_block - 1) / fp.tiles_per_block;
 		const bool timed = h->profiling && h->ev_used < kEventPairs;
@@ -1366,21 +1376,7 @@ restart_direct:
 				// One workgroup per CU is resident (128 KiB of LDS), so the launch runs in rounds
 				// of `cus` workgroups: pick the row-chunk count that minimises
 				// rounds x (steps per workgroup + ~2 steps of prologue).
-				uint32_t gchunks = 1;
-				{
-					const uint32_t gmax = std::max<uint32_t>(1, gp.n_tiles_sel / 4);
-					double best = 1e300;
-					for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 1024); ++g) {
-						const uint32_t steps = (gp.n_tiles_sel + g - 1) / g;
-						const uint64_t blocks = (uint64_t)g * gp.n_qtiles;
-						const uint64_t rounds = (blocks + cus - 1) / cus;
-						const double cost = (double)rounds * (steps + 2.0);
-						if (cost < best * 0.999) {
-							best = cost;
-							gchunks = g;
-						}
-					}
-				}
+				uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 1024, 0, nullptr);
 				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)
@@ -1401,34 +1397,9 @@ restart_direct:
 						fp.n_tiles_sel = (fp.n_tiles_sel / 16) * 16;
 					}
 					fp.n_qtiles = (uint32_t)((m + gvf->wgq - 1) / gvf->wgq);
-					uint32_t fchunks = 1;
-					{
-						const uint32_t slots = (uint32_t)gvf->wg_per_cu * (uint32_t)cus;
-						const uint32_t gmax = std::max<uint32_t>(1, fp.n_tiles_sel / 8);
-						double best = 1e300;
-						double best8 = 1e300;
-						uint32_t g8 = 0;
-						for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 2048); ++g) {
-							const uint32_t steps = (fp.n_tiles_sel + g - 1) / g;
-							const uint64_t blocks = (uint64_t)g * fp.n_qtiles;
-							const uint64_t rounds = (blocks + slots - 1) / slots;
-							const double cost = (double)rounds * (steps + 4.0);
-							if (cost < best * 0.999) {
-								best = cost;
-								fchunks = g;
-							}
-							// a multiple of 8 whose rounding leaves exactly g chunks: XCD-aware placement
-							if (g % 8 == 0 && cost < best8 * 0.999 &&
-							    (fp.n_tiles_sel + steps - 1) / steps == g) {
-								best8 = cost;
-								g8 = g;
-							}
-						}
-						if (g8 && best8 <= best * (1.0 + 0.01 * (double)h->opt_xcd_tolerance) && !(h->opt_debug & 1024)) {
-							fchunks = g8;
-							fp.xcd_map = 1;
-						}
-					}
+					uint32_t fchunks = pick_row_chunks(fp.n_tiles_sel, fp.n_qtiles, (uint32_t)gvf->wg_per_cu * (uint32_t)cus,
+					                                   4.0, 8, 2048, h->opt_xcd_tolerance,
+					                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
 					if (h->opt_scan_chunks > 0) {  // (experiments: force the row-chunk count)
 						fchunks = (uint32_t)std::min<long>(h->opt_scan_chunks, std::max<uint32_t>(1, fp.n_tiles_sel / 8));
 						fp.xcd_map = (fchunks % 8 == 0 && !(h->opt_debug & 1024)) ? 1 : 0;
@@ -1540,21 +1511,7 @@ restart_direct:
 				gp.cand_cnt = h->d_cnt;
 				gp.cand = h->d_cand;
 				gp.cap = cap;
-				uint32_t gchunks = 1;
-				{
-					const uint32_t gmax = std::max<uint32_t>(1, gp.n_tiles_sel / 4);
-					double best = 1e300;
-					for (uint32_t g = 1; g <= std::min<uint32_t>(gmax, 4096); ++g) {
-						const uint32_t steps = (gp.n_tiles_sel + g - 1) / g;
-						const uint64_t blocks = (uint64_t)g * gp.n_qtiles;
-						const uint64_t rounds = (blocks + cus - 1) / cus;
-						const double cost = (double)rounds * (steps + 2.0);
-						if (cost < best * 0.999) {
-							best = cost;
-							gchunks = g;
-						}
-					}
-				}
+				uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 4096, 0, nullptr);
 				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
 				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
 				if (timed)
