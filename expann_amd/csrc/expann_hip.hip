@@ -1105,6 +1105,87 @@ int sampled_pass_f16(expann_index* h, const GemmF16Variant* gvf, size_t m, size_
 	return EXPANN_OK;
 }
 
+// The fp16-form scan of one threshold level (theta' is in h->d_theta): the MFMA kernel of the
+// index's dimension over `rows_sel` sampled rows (last: all rows), or -- a handful of queries on
+// the last level -- the same filter streamed from HBM (scan_direct_f16.hpp).
+int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_sel, bool last, size_t m, int cus,
+                    bool ip, uint32_t cap, hipStream_t st, const char** kname, uint32_t* n_qtiles,
+                    uint32_t* query_tile) {
+	*query_tile = (uint32_t)gvf->wgq;
+	// 64-row tiles, 256 queries per workgroup, two workgroups resident per CU
+	GemmF16Params fp{};
+	fp.base_f16 = h->d_base_f16;
+	fp.bnorm = h->d_bnorm_f16;
+	fp.n_rows = (uint32_t)h->n;
+	const uint32_t nt = (uint32_t)((h->n + gvf->tb - 1) / gvf->tb);
+	fp.n_tiles_sel = last ? nt : std::min(nt, (rows_sel + gvf->tb - 1) / gvf->tb);
+	fp.tile_stride = std::max<uint32_t>(1, nt / fp.n_tiles_sel);
+	fp.tile_run = 1;
+	if (!last && fp.tile_stride >= 16 && fp.n_tiles_sel >= 16) {
+		// sampled level: runs of 16 consecutive tiles (one 256 KiB stretch each at d = 128)
+		fp.tile_run = 16;
+		fp.n_tiles_sel = (fp.n_tiles_sel / 16) * 16;
+	}
+	fp.n_qtiles = (uint32_t)((m + gvf->wgq - 1) / gvf->wgq);
+	uint32_t fchunks = pick_row_chunks(fp.n_tiles_sel, fp.n_qtiles, (uint32_t)gvf->wg_per_cu * (uint32_t)cus,
+	                                   4.0, 8, 2048, h->opt_xcd_tolerance,
+	                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
+	if (h->opt_scan_chunks > 0) {  // (experiments: force the row-chunk count)
+		fchunks = (uint32_t)std::min<long>(h->opt_scan_chunks, std::max<uint32_t>(1, fp.n_tiles_sel / 8));
+		fp.xcd_map = (fchunks % 8 == 0 && !(h->opt_debug & 1024)) ? 1 : 0;
+		const uint32_t tpb = (fp.n_tiles_sel + fchunks - 1) / fchunks;
+		if ((fp.n_tiles_sel + tpb - 1) / tpb != fchunks)
+			fp.xcd_map = 0;
+	}
+	fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;
+	fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
+	fp.queries_f16 = h->d_q_split;
+	fp.theta = h->d_theta;
+	fp.two_inv_s2 = (ip ? 1.0f : 2.0f) / (h->f16_scale * h->f16_scale);
+	fp.m = (uint32_t)m;
+	fp.cand_cnt = h->d_cnt;
+	fp.cand = h->d_cand;
+	fp.cap = cap;
+	fp.debug = (uint32_t)h->opt_debug & ~16u;
+	DevBuf clk;
+	if (h->opt_debug & 16) {
+		HIP_TRY(h, clk.alloc(18 * 8));
+		HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
+		fp.clk = clk.as<unsigned long long>();
+	}
+	const DirectF16Variant* dv =
+	    (last && h->opt_scan_kernel == 0) ? pick_direct_f16(h->dim, m) : nullptr;
+	if (dv) {
+		// a handful of queries: stream the fp16 rows without the matrix cores, ~16
+		// workgroups per CU, whole RPS-row steps (inside the copy's 64-row padding)
+		fp.n_qtiles = (uint32_t)((m + dv->tq - 1) / dv->tq);
+		fp.n_tiles_sel = (uint32_t)((h->n + dv->rps - 1) / dv->rps);
+		const uint32_t want = std::max<uint32_t>(1, (16u * (uint32_t)cus) / fp.n_qtiles);
+		fp.tiles_per_block = std::max<uint32_t>(8, (fp.n_tiles_sel + want - 1) / want);
+		fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
+		fp.xcd_map = 0;
+		hipLaunchKernelGGL(dv->fn, dim3(fchunks * fp.n_qtiles), dim3(kBlock), 0, st, fp);
+		*kname = dv->name;
+		*query_tile = (uint32_t)dv->tq;
+	} else {
+		hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
+		                   st, fp);
+		*kname = gvf->name;
+	}
+	*n_qtiles = fp.n_qtiles;
+	if (fp.clk) {
+		int occ = -1;
+		hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gvf->scan, gvf->threads, gvf->lds);
+		std::fprintf(stderr, "scan_gemm_f16: %d workgroups per CU resident, grid %u\n", occ,
+		             fchunks * fp.n_qtiles);
+		unsigned long long c[18] = {0};
+		HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
+		             c[1] / 100.0, c[1] ? c[0] * 100.0 / c[1] : 0.0);
+	}
+	return EXPANN_OK;
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
@@ -1382,77 +1463,10 @@ restart_direct:
 				if (timed)
 					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
 				if (gvf) {
-					// 64-row tiles, 256 queries per workgroup, two workgroups resident per CU
-					GemmF16Params fp{};
-					fp.base_f16 = h->d_base_f16;
-					fp.bnorm = h->d_bnorm_f16;
-					fp.n_rows = gp.n_rows;
-					const uint32_t nt = (uint32_t)((h->n + gvf->tb - 1) / gvf->tb);
-					fp.n_tiles_sel = last ? nt : std::min(nt, (L.n_groups_sel * kRowsPerGroup + gvf->tb - 1) / gvf->tb);
-					fp.tile_stride = std::max<uint32_t>(1, nt / fp.n_tiles_sel);
-					fp.tile_run = 1;
-					if (!last && fp.tile_stride >= 16 && fp.n_tiles_sel >= 16) {
-						// sampled level: runs of 16 consecutive tiles (one 256 KiB stretch each at d = 128)
-						fp.tile_run = 16;
-						fp.n_tiles_sel = (fp.n_tiles_sel / 16) * 16;
-					}
-					fp.n_qtiles = (uint32_t)((m + gvf->wgq - 1) / gvf->wgq);
-					uint32_t fchunks = pick_row_chunks(fp.n_tiles_sel, fp.n_qtiles, (uint32_t)gvf->wg_per_cu * (uint32_t)cus,
-					                                   4.0, 8, 2048, h->opt_xcd_tolerance,
-					                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
-					if (h->opt_scan_chunks > 0) {  // (experiments: force the row-chunk count)
-						fchunks = (uint32_t)std::min<long>(h->opt_scan_chunks, std::max<uint32_t>(1, fp.n_tiles_sel / 8));
-						fp.xcd_map = (fchunks % 8 == 0 && !(h->opt_debug & 1024)) ? 1 : 0;
-						const uint32_t tpb = (fp.n_tiles_sel + fchunks - 1) / fchunks;
-						if ((fp.n_tiles_sel + tpb - 1) / tpb != fchunks)
-							fp.xcd_map = 0;
-					}
-					fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;
-					fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
-					fp.queries_f16 = h->d_q_split;
-					fp.theta = gp.theta;
-					fp.two_inv_s2 = (ip ? 1.0f : 2.0f) / (h->f16_scale * h->f16_scale);
-					fp.m = gp.m;
-					fp.cand_cnt = gp.cand_cnt;
-					fp.cand = gp.cand;
-					fp.cap = gp.cap;
-					fp.debug = (uint32_t)h->opt_debug & ~16u;
-					DevBuf clk;
-					if (h->opt_debug & 16) {
-						HIP_TRY(h, clk.alloc(18 * 8));
-						HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
-						fp.clk = clk.as<unsigned long long>();
-					}
-					const DirectF16Variant* dv =
-					    (last && h->opt_scan_kernel == 0) ? pick_direct_f16(h->dim, m) : nullptr;
-					if (dv) {
-						// a handful of queries: stream the fp16 rows without the matrix cores, ~16
-						// workgroups per CU, whole RPS-row steps (inside the copy's 64-row padding)
-						fp.n_qtiles = (uint32_t)((m + dv->tq - 1) / dv->tq);
-						fp.n_tiles_sel = (uint32_t)((h->n + dv->rps - 1) / dv->rps);
-						const uint32_t want = std::max<uint32_t>(1, (16u * (uint32_t)cus) / fp.n_qtiles);
-						fp.tiles_per_block = std::max<uint32_t>(8, (fp.n_tiles_sel + want - 1) / want);
-						fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
-						fp.xcd_map = 0;
-						hipLaunchKernelGGL(dv->fn, dim3(fchunks * fp.n_qtiles), dim3(kBlock), 0, st, fp);
-						kname = dv->name;
-						tq_small = (uint32_t)dv->tq;
-					} else {
-						hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
-						                   st, fp);
-						kname = gvf->name;
-					}
-					gp.n_qtiles = fp.n_qtiles;
-					if (fp.clk) {
-						int occ = -1;
-						hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gvf->scan, gvf->threads, gvf->lds);
-						std::fprintf(stderr, "scan_gemm_f16: %d workgroups per CU resident, grid %u\n", occ,
-						             fchunks * fp.n_qtiles);
-						unsigned long long c[18] = {0};
-						HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
-						std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
-						             c[1] / 100.0, c[1] ? c[0] * 100.0 / c[1] : 0.0);
-					}
+					const int rl = launch_scan_f16(h, gvf, L.n_groups_sel * kRowsPerGroup, last, m, cus, ip, cap, st, &kname,
+					                               &gp.n_qtiles, &tq_small);
+					if (rl != EXPANN_OK)
+						return rl;
 				} else if (gvb) {
 					GemmBf16Params bp{};
 					bp.base_split = h->d_base_split;
@@ -1489,7 +1503,7 @@ restart_direct:
 					kname = gv->name;
 				}
 				passes = gp.n_qtiles;
-				qt_used = tq_small ? tq_small : tq_wg;
+				qt_used = tq_small ? tq_small : tq_wg;  // (launch_scan_f16 reports the tile it used)
 			} else if (gvi && !first) {
 				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 				                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,
