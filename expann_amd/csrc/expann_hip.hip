@@ -76,6 +76,7 @@ struct expann_index {
 	// select kernels store the results straight into it, so a search costs one async H2D copy of
 	// the queries, the kernels, and the flag read-back -- one host sync, no pageable copies
 	void* h_pin = nullptr;
+	bool q_in_pinned_host = false;  // (expann_search -> search_pass: d_queries is pinned host memory)
 	uint32_t* d_ticket = nullptr;  // last-workgroup counter of sample_direct_f16_kernel (0 between launches)
 	size_t h_pin_bytes = 0;
 	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
@@ -382,7 +383,7 @@ const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16x3_kernel<64>, "scan_gem
 
 using GemmF16Fn = void (*)(GemmF16Params);
 using SqnormFn = void (*)(const float*, uint32_t, float*);
-using F16PrepFn = void (*)(const float*, uint32_t, float, _Float16*, float*, uint32_t*);
+using F16PrepFn = void (*)(const float*, uint32_t, float, _Float16*, float*, uint32_t*, float*, uint32_t*);
 struct GemmF16Variant {
 	int d;
 	GemmF16Fn scan;
@@ -1324,12 +1325,22 @@ restart_direct:
 		}
 		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end):
 		// one memset of the flag block, one kernel
-		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, 32, st));
+		// (latency mode, one workgroup: the kernel clears the flag block itself and, when the queries
+		// still sit in pinned host memory, leaves the device copy the later kernels read)
+		const bool one_wg = m <= (size_t)kRowsPerGroup;
+		const bool from_host = h->q_in_pinned_host && one_wg;
+		if (!one_wg)
+			HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, 32, st));
 		flags_clean = true;
 		hipLaunchKernelGGL(gvf->prep, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)), dim3(kBlock),
 		                   0, st, (const float*)d_queries, (uint32_t)m, h->f16_scale, (_Float16*)h->d_q_split,
-		                   h->d_qnrm, h->d_overflow + 2);
+		                   h->d_qnrm, h->d_overflow + 2, from_host ? (float*)h->d_q : (float*)nullptr,
+		                   one_wg ? h->d_overflow : (uint32_t*)nullptr);
 		HIP_TRY(h, hipGetLastError());
+		if (from_host) {
+			d_queries = h->d_q;
+			h->q_in_pinned_host = false;
+		}
 	}
 	if (gvb) {  // queries -> bf16 hi/lo planes
 		const size_t nv = m * (size_t)h->dim;
@@ -1994,10 +2005,23 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 		}
 		char* pin = (char*)h->h_pin;
 		std::memcpy(pin, queries, qbytes);
-		HIP_TRY(h, hipMemcpyAsync(h->d_q, pin, qbytes, hipMemcpyHostToDevice, h->stream));
+		// fp32 index with its fp16 copy in place and at most one workgroup of queries: the query
+		// prep kernel reads them straight from pinned memory (and makes the device copy); otherwise
+		// one async copy
+		const void* dq = h->d_q;
+		if (h->dtype == EXPANN_DTYPE_F32 && h->d_base_f16 && h->f16_scale > 0.0f && h->opt_scan_kernel == 0 &&
+		    m <= (size_t)kRowsPerGroup && h->n >= 4096 && pick_gemm(h, m) != nullptr) {
+			h->q_in_pinned_host = true;
+			dq = pin;
+		} else {
+			HIP_TRY(h, hipMemcpyAsync(h->d_q, pin, qbytes, hipMemcpyHostToDevice, h->stream));
+		}
 		// (search_pass ends with the flag read-back and a stream sync: the results are complete)
-		int rc = expann_search_device(h, h->d_q, m, k, (uint64_t*)(pin + ids_off), (float*)(pin + dists_off),
+		int rc = expann_search_device(h, dq, m, k, (uint64_t*)(pin + ids_off), (float*)(pin + dists_off),
 		                              h->stream);
+		if (h->q_in_pinned_host) {  // (a path that did not run the prep kernel read the queries over PCIe)
+			h->q_in_pinned_host = false;
+		}
 		if (rc != EXPANN_OK)
 			return rc;
 		std::memcpy(ids, pin + ids_off, sizeof(uint64_t) * m * k);

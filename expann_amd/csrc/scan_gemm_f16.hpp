@@ -113,11 +113,20 @@ __global__ __launch_bounds__(kBlock) void sqnorm_kernel(const float* x, uint32_t
 }
 // Query side of a search in ONE launch: scaled fp16 copy, ||q||^2 in the reference lane order and
 // the bit pattern of max |q| (range check).  16 lanes per query row, as sqnorm_kernel.
+// Latency mode (m <= 16: a single workgroup): q may be pinned host memory -- the kernel then also
+// leaves a device copy in q_copy for the kernels that follow -- and zero_flags (the 8-word flag /
+// statistics block that maxabs_bits points into) is cleared here instead of by a memset launch.
 template <int D>
 __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, uint32_t m, float scale,
                                                                 _Float16* q16, float* qnrm,
-                                                                uint32_t* maxabs_bits) {
+                                                                uint32_t* maxabs_bits, float* q_copy,
+                                                                uint32_t* zero_flags) {
 	__shared__ uint32_t red[kBlock / 64];
+	if (zero_flags) {
+		if (threadIdx.x < 8)
+			zero_flags[threadIdx.x] = 0;
+		__syncthreads();
+	}
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int l = lane & 15, rg = lane >> 4;
 	const uint32_t i = blockIdx.x * kRowsPerGroup + wave * kRowsPerWaveStep + rg;
@@ -131,8 +140,11 @@ __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, 
 		acc = __builtin_fmaf(v, v, acc);
 		const uint32_t vb = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
 		b = vb > b ? vb : b;
-		if (i < m)
+		if (i < m) {
 			q16[(size_t)i * D + l + 16 * t] = (_Float16)(v * scale);
+			if (q_copy)
+				q_copy[(size_t)i * D + l + 16 * t] = v;
+		}
 	}
 	acc = reduce16_ref_order(acc);
 	if (i < m && l == 0)
