@@ -203,7 +203,10 @@ int expann_get_profile(expann_index* h, expann_profile* out);
  * exact 8-bit kernels -- same ids and fp32 distances; 0: never),
  * "latency_mode" (1 (default): expann_search with few queries (m*k <= 16384) stages them in
  * pinned memory and lets the select kernels store the results there -- one host sync per
- * search and no pageable copies; 0: always the plain copy path). */
+ * search and no pageable copies; 0: always the plain copy path),
+ * "xcd_tolerance" (percent of modelled launch cost given up for an XCD-aligned row-chunk count,
+ * default 3), "scan_chunks" (experiments: force the row-chunk count of the fp16 scan; 0 = model),
+ * "sample_run", "debug" (bench / ablation switches). */
 int expann_set_option(expann_index* h, const char* name, long value);
 
 #ifdef __cplusplus
