@@ -747,30 +747,15 @@ __device__ inline void sample_tau_query(const SampleTauParams& p, uint32_t qi, i
 		// larger g first: order by ~ordered(g); the index keeps equal values apart
 		keys[j] = i < p.n_vals ? ((uint64_t)float_to_ordered(v[i]) << 32) | (0xFFFFFFFFu - i) : 0ull;
 	}
-	uint64_t kth = 0;
-	if (p.k > 24 || PER >= 16) {  // bisection on the value: 32 steps whatever k and list length
-		uint32_t ord[PER];
+	// bisection on the ordered value (32 steps whatever k and the list length; k <= 64: over the few
+	// values that reach the k-th largest lane maximum)
+	uint32_t ord[PER];
 #pragma unroll
-		for (int j = 0; j < PER; ++j)
-			ord[j] = (uint32_t)(keys[j] >> 32);
-		kth = (uint64_t)(p.k <= 64 ? wave_kth_largest_sparse_u32<PER>(ord, p.k, scratch, lane)
-		                           : wave_kth_largest_u32<PER>(ord, p.k))
-		      << 32;
-	} else
-	for (uint32_t it = 0; it < p.k; ++it) {
-		uint64_t best = 0;
-#pragma unroll
-		for (int j = 0; j < PER; ++j)
-			best = keys[j] > best ? keys[j] : best;
-		for (int off = 32; off > 0; off >>= 1) {
-			const uint64_t o = __shfl_xor(best, off);
-			best = o > best ? o : best;
-		}
-		kth = best;
-#pragma unroll
-		for (int j = 0; j < PER; ++j)
-			keys[j] = keys[j] == best ? 0ull : keys[j];
-	}
+	for (int j = 0; j < PER; ++j)
+		ord[j] = (uint32_t)(keys[j] >> 32);
+	const uint64_t kth = (uint64_t)(p.k <= 64 ? wave_kth_largest_sparse_u32<PER>(ord, p.k, scratch, lane)
+	                                          : wave_kth_largest_u32<PER>(ord, p.k))
+	                     << 32;
 	if (lane == 0)
 		sample_tau_finish(p, qi, (uint32_t)(kth >> 32));
 }
