@@ -173,8 +173,11 @@ def bench_c4(a):
     import subprocess
     import numpy as np
     tool = os.path.join(ROOT, "expann_amd", "host", "expann_graph_tool")
-    out_dir = os.path.join(ROOT, "gpurun_out", "c4")
-    os.makedirs(out_dir, exist_ok=True)
+    import atexit
+    import shutil
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="expann_c4_")   # index + query files: tens of MB, scratch only
+    atexit.register(shutil.rmtree, out_dir, ignore_errors=True)
     n = a.n if a.n != 1_000_000 else 20_000
     idx, qf = os.path.join(out_dir, "c4.index"), os.path.join(out_dir, "c4.queries")
     efs = [a.k * mult for mult in (1, 2, 3, 4, 5, 6)]       # src/bench_runner.h:134
