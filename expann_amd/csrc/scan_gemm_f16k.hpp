@@ -24,6 +24,9 @@
 #pragma once
 #include "scan_gemm_f16.hpp"
 
+#ifndef EXPANN_F16K_FD
+#define EXPANN_F16K_FD 2
+#endif
 namespace expann {
 
 template <int D> struct F16kGeom {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 		};
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + 1, srow0);
-		constexpr int FD = 2;  // k-steps of fragment read-ahead
+		constexpr int FD = EXPANN_F16K_FD;  // k-steps of fragment read-ahead
 		f16x8 fb[KSB];
 #pragma unroll
 		for (int s = 0; s < FD; ++s)
