@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--sample-frac", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--xcd-tolerance", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--scan-chunks", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sync-search", action="store_true",
+                    help="wait for every search before enqueuing what follows (default: deferred check, "
+                         "one expann_sync at the end of the timed steps)")
     ap.add_argument("--sample-run", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sift-like", action="store_true",
                     help="f32 rows and queries hold integers 0..255 (SURVEY 8d's SIFT stand-in)")
@@ -299,7 +302,17 @@ def main():
     from expann_amd.sharded import GridShardedSearch, chunk_bytes, unpack_chunk
     from expann_amd import merge_topk_strided_device
     bufs = {}
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything of a step -- the engine's kernels, the merge, the collectives' stream dependencies --
+    # is ordered on ONE explicit stream (torch's default stream has handle 0, which the engine would
+    # replace by a stream of its own)
+    torch.cuda.synchronize()
+    work_stream = torch.cuda.Stream(device=dev)
+    stream = work_stream.cuda_stream
+    use_async = not a.sync_search and not os.environ.get("EXPANN_BENCH_REHEARSAL")
+    if use_async:
+        # deferred check: a search is enqueued without a host wait, so the next kernels / the RCCL
+        # exchange are already queued when it ends; expann_sync validates all steps at the end
+        eng.set_option("async_search", 1)
     cb = chunk_bytes(pad, a.k)
 
     def alloc(name, nbytes, like):
@@ -323,25 +336,53 @@ def main():
     ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
 
     def step():
-        ss.search(queries, a.k)
+        with torch.cuda.stream(work_stream):
+            ss.search(queries, a.k)
+
+    def timed(n_steps):
+        """(seconds, ok): ok is False when a deferred search of the loop needed the synchronous
+        retry (agreed between the ranks: every rank then repeats the steps the waiting way)"""
+        if G > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        ok = True
+        if use_async:
+            try:
+                eng.sync()      # every deferred search of the loop is complete and valid
+            except RuntimeError as e:
+                print(f"bench: {e}", file=sys.stderr)
+                ok = False
+        torch.cuda.synchronize()
+        if G > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t_start
+        if G > 1:
+            flag = torch.tensor([0 if ok else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            ok = int(flag.item()) == 0
+        return dt, ok
 
     # one-time lazy initialisation outside any count: derived copies of the index (fp16 / uint8),
     # workspace allocation and -- with G > 1 -- the communicators of the two process groups
     step()
+    if use_async:
+        eng.sync()
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
+    if use_async:
+        eng.sync()
     eng.set_profiling(True)
-    if G > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if G > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, ok = timed(a.steps)
+    if not ok:   # (never on the synthetic workloads) time the waiting form instead
+        print("bench: repeating the timed steps with --sync-search", file=sys.stderr)
+        use_async = False
+        eng.set_option("async_search", 0)
+        eng.get_profile()
+        elapsed, _ = timed(a.steps)
     if G > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,7 +390,10 @@ def main():
     prof = eng.get_profile()
     eng.set_profiling(False)
     if a.verify and a.dtype == "f32":
-        got_ids, got_d = ss.search(queries, a.k)
+        with torch.cuda.stream(work_stream):
+            got_ids, got_d = ss.search(queries, a.k)
+        if use_async:
+            eng.sync()
         torch.cuda.synchronize()
         if rank == 0:
             parts = []
@@ -453,6 +497,9 @@ def main():
                                       f"{a.m} batched queries, k={a.k} (BASELINE "
                                       f"{'configs[1]' if a.workload == 'c2' else 'configs[4]'})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
+                          "host_sync": ("deferred: searches are enqueued back to back, one expann_sync "
+                                        "validates all K steps inside the timed region") if use_async
+                          else "per step",
                           "sharding": (f"rows/{R} x queries/{Q} (rank 0 scans {n_local} rows for {m_local} "
                                        f"queries; roofline figures are rank 0's launch)")
                           if G > 1 else "none"},

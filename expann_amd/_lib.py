@@ -16,7 +16,7 @@ METRIC_L2, METRIC_IP, METRIC_L2_I8_REFCOMPAT = 0, 1, 2
 ABI_SYMBOLS = [
     "expann_abi_version", "expann_device_count", "expann_create", "expann_destroy",
     "expann_last_error", "expann_add", "expann_build", "expann_set_base_device", "expann_size",
-    "expann_search", "expann_search_device", "expann_merge_topk_device", "expann_merge_topk_strided_device", "expann_score_ids",
+    "expann_search", "expann_search_device", "expann_sync", "expann_merge_topk_device", "expann_merge_topk_strided_device", "expann_score_ids",
     "expann_set_profiling", "expann_get_profile", "expann_set_option",
     "expann_quantize_simple_u8_device", "expann_quantize_ranged_q8_device",
     "expann_graph_create", "expann_graph_destroy", "expann_graph_last_error",
@@ -72,6 +72,8 @@ def load():
     L.expann_size.argtypes = [vp]
     L.expann_search.restype = C.c_int
     L.expann_search.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.expann_sync.restype = C.c_int
+    L.expann_sync.argtypes = [vp]
     L.expann_search_device.restype = C.c_int
     L.expann_search_device.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.expann_merge_topk_device.restype = C.c_int

@@ -39,6 +39,7 @@ namespace {
 constexpr uint32_t kMaxCap = 16384;      // keys per query that fit the select kernel's LDS
 constexpr size_t kMaxQueriesPerPass = 32768;
 constexpr int kEventPairs = 64;
+constexpr uint32_t kAsyncRing = 64;  // outstanding searches of the deferred-check mode
 
 struct Level {
 	uint32_t n_groups_sel;
@@ -115,6 +116,12 @@ struct expann_index {
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
 	long opt_scan_chunks = 0;
+	// deferred check (expann_sync): flag blocks of the outstanding searches, read back into a ring
+	long opt_async = 0;
+	bool host_call = false;          // (expann_search: always the synchronous path)
+	uint32_t* h_flag_ring = nullptr; // pinned [kAsyncRing][8]
+	uint32_t async_pending = 0;
+	hipStream_t async_stream = nullptr;
 	long opt_xcd_tolerance = 3;  // % of modelled cost given up for an XCD-aligned chunk count
 	long opt_latency_mode = 1;  // few queries from host buffers: results land in pinned memory
 	long opt_debug = 0;
@@ -344,6 +351,7 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
 		h->d_total = reinterpret_cast<unsigned long long*>(h->d_overflow + 4);
 		HIP_TRY(h, hipHostMalloc((void**)&h->h_flags, sizeof(uint32_t) * 8, 0));
+		HIP_TRY(h, hipHostMalloc((void**)&h->h_flag_ring, sizeof(uint32_t) * 8 * kAsyncRing, 0));
 		HIP_TRY(h, hipMalloc(&h->d_ticket, sizeof(uint32_t)));
 		HIP_TRY(h, hipMemset(h->d_ticket, 0, sizeof(uint32_t)));
 		HIP_TRY(h, hipDeviceSynchronize());  // (once per handle: the counter is zero before any stream uses it)
@@ -605,6 +613,19 @@ void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t s
 		hipLaunchKernelGGL((select_wave_kernel<32, 1>), dim3((uint32_t)m), dim3(64), 0, st, sel, (uint32_t)m);
 		sel.wave_done = 2048;
 	}
+}
+
+// Deferred check: the flag block of this search goes to the next ring slot and the call returns
+// without waiting; expann_sync looks at the slots.  False when the caller has to wait as usual.
+bool defer_flags(expann_index* h, hipStream_t st, int attempt) {
+	if (!h->opt_async || h->host_call || attempt != 0 || h->strict_u8 || h->async_pending >= kAsyncRing)
+		return false;
+	if (hipMemcpyAsync(h->h_flag_ring + 8 * h->async_pending, h->d_overflow,
+	                   sizeof(uint32_t) * 4 + sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess)
+		return false;
+	h->async_pending++;
+	h->async_stream = st;
+	return true;
 }
 
 // Row-chunk count of a tiled scan.  `slots` workgroups are resident at a time, so a launch of
@@ -891,6 +912,10 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock), sizeof(uint64_t) * cap + 16,
 		                   st, sel);
 		HIP_TRY(h, hipGetLastError());
+		if (defer_flags(h, st, attempt)) {  // deferred check: expann_sync reads the flags
+			h->h_flag_ring[8 * (h->async_pending - 1) + 6] = 0;
+			return EXPANN_OK;
+		}
 		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
 		                          hipMemcpyDeviceToHost, st));
 		HIP_TRY(h, hipStreamSynchronize(st));
@@ -1608,6 +1633,11 @@ restart_direct:
 			HIP_TRY(h, hipGetLastError());
 		}
 		// overflow check (the only host sync of a search); flags and statistics are contiguous
+		if (defer_flags(h, st, attempt)) {  // deferred check: expann_sync reads the flags
+			float sc = gvf ? h->f16_scale : 0.0f;  // (fp16 form: the range check of max |q| needs the scale)
+			std::memcpy(&h->h_flag_ring[8 * (h->async_pending - 1) + 6], &sc, sizeof(float));
+			return EXPANN_OK;
+		}
 		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
 		                          hipMemcpyDeviceToHost, st));
 		HIP_TRY(h, hipStreamSynchronize(st));
@@ -1829,6 +1859,7 @@ void expann_destroy(expann_index* h) {
 	if (h->d_qself) hipFree(h->d_qself);
 	if (h->d_theta) hipFree(h->d_theta);
 	if (h->h_flags) hipHostFree(h->h_flags);
+	if (h->h_flag_ring) hipHostFree(h->h_flag_ring);
 	if (h->h_pin) hipHostFree(h->h_pin);
 	if (h->d_ticket) hipFree(h->d_ticket);
 	if (h->d_q) hipFree(h->d_q);
@@ -1970,6 +2001,35 @@ int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_
 	return EXPANN_OK;
 }
 
+int expann_sync(expann_index* h) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (h->async_pending == 0)
+		return EXPANN_OK;
+	HIP_TRY(h, hipSetDevice(h->device));
+	const uint32_t n = h->async_pending;
+	h->async_pending = 0;
+	HIP_TRY(h, hipStreamSynchronize(h->async_stream));
+	uint32_t bad = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t* f = h->h_flag_ring + 8 * i;
+		float qmax, scale;
+		std::memcpy(&qmax, &f[2], sizeof(float));
+		std::memcpy(&scale, &f[6], sizeof(float));
+		if (f[0] != 0 || f[1] != 0 || (scale > 0.0f && !(qmax * scale <= 60000.0f)))
+			++bad;
+		unsigned long long tot;
+		std::memcpy(&tot, f + 4, sizeof(tot));
+		h->prof.candidates = tot;
+	}
+	if (bad)
+		return h->fail(EXPANN_ERR_OVERFLOW, std::to_string(bad) + " of " + std::to_string(n) +
+		                                        " deferred searches need the synchronous retry "
+		                                        "(candidate overflow or queries outside the filter's range): "
+		                                        "repeat them with async_search = 0");
+	return EXPANN_OK;
+}
+
 int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint64_t* ids,
                   float* dists) {
 	if (!h)
@@ -1982,6 +2042,11 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 		return EXPANN_OK;
 	if (!queries || !ids)
 		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
+	if (h->async_pending) {  // deferred searches first
+		const int rs = expann_sync(h);
+		if (rs != EXPANN_OK)
+			return rs;
+	}
 	HIP_TRY(h, hipSetDevice(h->device));
 	const size_t qbytes = m * (size_t)h->dim * h->q_elem;
 	if (qbytes > h->io_q_bytes) {
@@ -2017,8 +2082,10 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 			HIP_TRY(h, hipMemcpyAsync(h->d_q, pin, qbytes, hipMemcpyHostToDevice, h->stream));
 		}
 		// (search_pass ends with the flag read-back and a stream sync: the results are complete)
+		h->host_call = true;
 		int rc = expann_search_device(h, dq, m, k, (uint64_t*)(pin + ids_off), (float*)(pin + dists_off),
 		                              h->stream);
+		h->host_call = false;
 		if (h->q_in_pinned_host) {  // (a path that did not run the prep kernel read the queries over PCIe)
 			h->q_in_pinned_host = false;
 		}
@@ -2040,7 +2107,9 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 		h->io_out = m * k;
 	}
 	HIP_TRY(h, hipMemcpyAsync(h->d_q, queries, qbytes, hipMemcpyHostToDevice, h->stream));
+	h->host_call = true;
 	int rc = expann_search_device(h, h->d_q, m, k, h->d_ids, h->d_dists, h->stream);
+	h->host_call = false;
 	if (rc != EXPANN_OK)
 		return rc;
 	HIP_TRY(h, hipMemcpyAsync(ids, h->d_ids, sizeof(uint64_t) * m * k, hipMemcpyDeviceToHost,
@@ -2220,6 +2289,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_u8_exact = value;
 	else if (!std::strcmp(name, "latency_mode"))
 		h->opt_latency_mode = value;
+	else if (!std::strcmp(name, "async_search"))
+		h->opt_async = value;
 	else if (!std::strcmp(name, "scan_chunks"))
 		h->opt_scan_chunks = value;
 	else if (!std::strcmp(name, "xcd_tolerance"))

@@ -83,6 +83,11 @@ class GpuBruteForceEngine:
             self._h, C.c_void_p(q_ptr), m, k, C.c_void_p(ids_ptr), C.c_void_p(dists_ptr),
             C.c_void_p(stream)))
 
+    def sync(self):
+        """expann_sync: wait for the searches enqueued under set_option("async_search", 1) and
+        report on them (raises if one needs the synchronous retry)."""
+        _lib.check(self._h, self._L.expann_sync(self._h))
+
     def score_ids(self, query, ids, cutoff=float("inf")):
         """quantized_scorer::filter_by_score (src/quantizer.h:20-59): (kept_ids, kept_scores)."""
         qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else _NP_DTYPE[self.dtype]

@@ -100,6 +100,16 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_t k,
                          uint64_t* d_ids, float* d_dists, void* stream);
 
+/* Deferred check (option "async_search" = 1, device-pointer searches only): expann_search_device
+ * enqueues the whole search and returns WITHOUT waiting, so the caller can enqueue what follows
+ * (the next batch, the RCCL exchange of a sharded job) while the GPU still scans.  expann_sync
+ * waits for the stream of the last such search and reports on all searches since the previous
+ * sync: EXPANN_OK, or EXPANN_ERR_OVERFLOW when one of them would have needed the synchronous
+ * retry (overflowed candidate lists, queries outside the fp16 range of the index): its results
+ * are then invalid and the caller repeats it with "async_search" = 0.  At most 64 searches may
+ * be outstanding (the 65th waits by itself). */
+int expann_sync(expann_index* h);
+
 /* k-way merge of per-shard results after an all-gather (RCCL): in_ids/in_dists are
  * [n_lists][m][k], each row ascending by (score, id) and padded as above; out is [m][k]. */
 int expann_merge_topk_device(int device, const uint64_t* d_in_ids, const float* d_in_dists,
@@ -204,6 +214,7 @@ int expann_get_profile(expann_index* h, expann_profile* out);
  * "latency_mode" (1 (default): expann_search with few queries (m*k <= 16384) stages them in
  * pinned memory and lets the select kernels store the results there -- one host sync per
  * search and no pageable copies; 0: always the plain copy path),
+ * "async_search" (1: expann_search_device returns without the final host wait, see expann_sync),
  * "xcd_tolerance" (percent of modelled launch cost given up for an XCD-aligned row-chunk count,
  * default 3), "scan_chunks" (experiments: force the row-chunk count of the fp16 scan; 0 = model),
  * "sample_run", "debug" (bench / ablation switches). */
