@@ -39,7 +39,7 @@ namespace {
 constexpr uint32_t kMaxCap = 16384;      // keys per query that fit the select kernel's LDS
 constexpr size_t kMaxQueriesPerPass = 32768;
 constexpr int kEventPairs = 64;
-constexpr uint32_t kAsyncRing = 64;  // outstanding searches of the deferred-check mode
+constexpr uint32_t kAsyncRing = 256;  // outstanding searches of the deferred-check mode
 
 struct Level {
 	uint32_t n_groups_sel;

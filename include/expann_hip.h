@@ -106,8 +106,8 @@ int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_
  * waits for the stream of the last such search and reports on all searches since the previous
  * sync: EXPANN_OK, or EXPANN_ERR_OVERFLOW when one of them would have needed the synchronous
  * retry (overflowed candidate lists, queries outside the fp16 range of the index): its results
- * are then invalid and the caller repeats it with "async_search" = 0.  At most 64 searches may
- * be outstanding (the 65th waits by itself). */
+ * are then invalid and the caller repeats it with "async_search" = 0.  At most 256 searches may
+ * be outstanding (further ones wait by themselves). */
 int expann_sync(expann_index* h);
 
 /* k-way merge of per-shard results after an all-gather (RCCL): in_ids/in_dists are
