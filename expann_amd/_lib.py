@@ -44,6 +44,42 @@ class ExpannError(RuntimeError):
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    PyTorch's ROCm wheels ship their OWN libamdhip64.so / libhsa-runtime64.so / librccl.so under
+    torch/lib (file name `libamdhip64.so`, SONAME `libamdhip64.so.7`), while libexpann_hip.so asks
+    for `libamdhip64.so.7` and finds /opt/rocm's.  The dynamic loader reuses an already loaded
+    object only when the REQUESTED name equals its file name or SONAME:
+      * torch first, library second: `libamdhip64.so.7` matches the SONAME of torch's copy -> one
+        runtime (how every bench / test of round 1 happened to run);
+      * library first, torch second: torch's `libamdhip64.so` matches neither name of /opt/rocm's
+        copy -> a SECOND HIP + HSA runtime is mapped, and the second one to initialise finds the
+        GPU already taken ("No HIP GPUs are available", the round-1 anomaly).
+    So when a torch installation with a bundled runtime exists and has not been loaded yet, its
+    runtime libraries are opened here first (by path, without importing torch): the library then
+    binds to them by SONAME, and a later `import torch` finds the very files already mapped."""
+    if "libamdhip64" in open("/proc/self/maps").read():
+        return  # a runtime is mapped already (torch imported first, or a second call)
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.origin:
+        return
+    tlib = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(tlib, name)
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def hip_runtimes_mapped():
+    """Distinct libamdhip64 files mapped into this process (must be 1 once the library is loaded)."""
+    return sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+
+
 def load():
     """Load libexpann_hip.so (raises if it has not been built)."""
     global _lib
@@ -52,6 +88,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     L.expann_abi_version.restype = C.c_int

@@ -62,11 +62,22 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 		return EXPANN_ERR_INVALID_ARG;
 	}
 	*out = nullptr;
-	if (!vectors || !layer_offsets || (!neighbours && layer_offsets[(size_t)n_layers * (n + 1) - 1]) ||
-	    n == 0 || n_layers == 0 || starting_vertex >= n || n >= (1ull << 32) - 64) {
+	if (!vectors || !layer_offsets || n == 0 || n_layers == 0 || starting_vertex >= n ||
+	    n >= (1ull << 32) - 64 || (!neighbours && layer_offsets[(size_t)n_layers * (n + 1) - 1])) {
 		g_create_error = "expann_graph_create: bad arguments";
 		return EXPANN_ERR_INVALID_ARG;
 	}
+	// CSR offsets: start at 0, never decrease (a corrupt index file must not turn into
+	// out-of-bounds reads on the device)
+	if (layer_offsets[0] != 0) {
+		g_create_error = "expann_graph_create: layer_offsets[0] != 0";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	for (size_t i = 1; i < (size_t)n_layers * (n + 1); ++i)
+		if (layer_offsets[i] < layer_offsets[i - 1]) {
+			g_create_error = "expann_graph_create: layer_offsets decrease";
+			return EXPANN_ERR_INVALID_ARG;
+		}
 	bool dim_ok = false;
 	for (const auto& v : kGraph)
 		dim_ok |= v.d == dim;
@@ -212,7 +223,7 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	uint32_t cand_cap = 256;
 	while (cand_cap < 16 * ef_search && cand_cap < 8192)
 		cand_cap *= 2;
-	for (int attempt = 0; attempt < 3; ++attempt) {
+	for (;;) {  // until no candidates heap overflows, or its LDS capacity limit (8192) is reached
 		GraphSearchParams p{};
 		p.vectors = g->d_vectors;
 		p.compressed = g->d_compressed;

@@ -349,6 +349,9 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 	if (!h->d_overflow) {
 		// flags [4 x u32] and statistics [2 x u64] share one allocation: one memset, one read-back
 		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
+		// every word starts at zero: the paths clear only the words they use, and expann_sync /
+		// the strict uint8 check read words 1..3 of searches that never wrote them
+		HIP_TRY(h, hipMemset(h->d_overflow, 0, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
 		h->d_total = reinterpret_cast<unsigned long long*>(h->d_overflow + 4);
 		HIP_TRY(h, hipHostMalloc((void**)&h->h_flags, sizeof(uint32_t) * 8, 0));
 		HIP_TRY(h, hipHostMalloc((void**)&h->h_flag_ring, sizeof(uint32_t) * 8 * kAsyncRing, 0));
@@ -623,6 +626,10 @@ bool defer_flags(expann_index* h, hipStream_t st, int attempt) {
 	if (hipMemcpyAsync(h->h_flag_ring + 8 * h->async_pending, h->d_overflow,
 	                   sizeof(uint32_t) * 4 + sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess)
 		return false;
+	// ring words 6 / 7 are the host's: 6 = fp16 scale of the search (set by the caller, 0 = none),
+	// 7 = 1 when word 1 (query values outside [0, 255]) belongs to this search (uint8 rows)
+	h->h_flag_ring[8 * h->async_pending + 6] = 0;
+	h->h_flag_ring[8 * h->async_pending + 7] = h->dtype == EXPANN_DTYPE_U8 ? 1u : 0u;
 	h->async_pending++;
 	h->async_stream = st;
 	return true;
@@ -1990,6 +1997,13 @@ int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_
 		return h->fail(EXPANN_ERR_INVALID_ARG, "NULL query/ids pointer");
 	HIP_TRY(h, hipSetDevice(h->device));
 	hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+	// all searches of a handle share one workspace: deferred searches still running on ANOTHER
+	// stream are drained before this one is enqueued (their flag blocks stay in the ring for
+	// expann_sync); on one stream the stream order does this
+	if (h->async_pending > 0 && h->async_stream != st) {
+		HIP_TRY(h, hipStreamSynchronize(h->async_stream));
+		h->async_stream = st;
+	}
 	const size_t qbytes = (size_t)h->dim * h->q_elem;
 	for (size_t q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
 		const size_t mm = std::min(kMaxQueriesPerPass, m - q0);
@@ -2016,7 +2030,7 @@ int expann_sync(expann_index* h) {
 		float qmax, scale;
 		std::memcpy(&qmax, &f[2], sizeof(float));
 		std::memcpy(&scale, &f[6], sizeof(float));
-		if (f[0] != 0 || f[1] != 0 || (scale > 0.0f && !(qmax * scale <= 60000.0f)))
+		if (f[0] != 0 || (f[7] != 0 && f[1] != 0) || (scale > 0.0f && !(qmax * scale <= 60000.0f)))
 			++bad;
 		unsigned long long tot;
 		std::memcpy(&tot, f + 4, sizeof(tot));

@@ -5,7 +5,7 @@
 //
 //   expann_graph_tool --n 5000 --m 200 --d 128 --k 10 --M 16 --ef_construction 100 \
 //       --data sift|gauss --index out.index --queries out.queries --results out.results \
-//       [--ef 10,20,40] [--build-only 1] [--read-index 1]
+//       [--ef 10,20,40] [--build-only 1] [--read-index 1] [--prune_overflow 0|1]
 //
 // Files: <queries> raw m*d float32; <results> for each (compression in {0,1}) x (ef in list):
 // m*k uint64 ids, m*k float32 dists, m uint32 distcomps, in that order.  One JSON line per
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
 	const size_t n = std::stoul(get("n", "2000")), m = std::stoul(get("m", "100")),
 	             d = std::stoul(get("d", "128")), k = std::stoul(get("k", "10"));
 	const size_t M = std::stoul(get("M", "16")), efc = std::stoul(get("ef_construction", "100"));
+	const size_t prune_overflow = std::stoul(get("prune_overflow", "0"));
 	const bool sift = get("data", "sift") == "sift";
 	const bool build_only = get("build-only", "0") == "1", read_index = get("read-index", "0") == "1";
 	const std::string index_path = get("index", "graph.index");
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
 	}
 
 	try {
-		gpu_antitopo_engine_config cfg(M, 2 * M, 1, efc, 1, 0.5f, 0.0f, 0);
+		gpu_antitopo_engine_config cfg(M, 2 * M, 1, efc, 1, 0.5f, 0.0f, prune_overflow);
 		cfg.index_filename = index_path;
 		cfg.read_index = read_index;
 		cfg.write_index = !read_index;

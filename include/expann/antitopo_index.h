@@ -170,6 +170,10 @@ struct antitopo_index {
 	std::vector<char> visited;
 	std::vector<size_t> visited_recent;
 	size_t num_distcomps = 0;
+	// the engine's sticky ef_search (src/antitopo_engine.h:189-195, :858-859): only serialised
+	// (:942-949), never loaded (":1000 search-time param, don't load")
+	bool has_ef_search = false;
+	size_t ef_search = 0;
 
 	antitopo_index() = default;
 	antitopo_index(size_t _dim, antitopo_config c) : conf(c), dim(_dim) {}
@@ -421,8 +425,12 @@ struct antitopo_index {
 		auto W = [&](const void* p, size_t n) { out.write(reinterpret_cast<const char*>(p), (std::streamsize)n); };
 		const uint64_t sv = starting_vertex, M = conf.M, M0 = conf.M0, efm = conf.ef_search_mult;
 		W(&sv, 8); W(&M, 8); W(&M0, 8); W(&efm, 8);
-		const uint8_t has_ef = 0;
+		const uint8_t has_ef = has_ef_search ? 1 : 0;
 		W(&has_ef, 1);
+		if (has_ef) {
+			const uint64_t efs = ef_search;
+			W(&efs, 8);
+		}
 		const uint64_t efc = conf.ef_construction, oc = conf.ortho_count, po = conf.prune_overflow,
 		               ml = max_layer;
 		W(&efc, 8); W(&oc, 8); W(&conf.ortho_factor, 4); W(&conf.ortho_bias, 4); W(&po, 8);

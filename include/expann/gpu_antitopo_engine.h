@@ -54,7 +54,11 @@ struct gpu_antitopo_engine : public ann_engine<T, gpu_antitopo_engine<T>> {
 	gpu_antitopo_engine& operator=(const gpu_antitopo_engine&) = delete;
 	~gpu_antitopo_engine() { expann_graph_destroy(graph); }
 
-	void set_ef_search(size_t e) { ef_search = e; }  // src/antitopo_engine.h:189-195
+	void set_ef_search(size_t e) {  // src/antitopo_engine.h:189-195
+		ef_search = e;
+		index.has_ef_search = true;
+		index.ef_search = e;
+	}
 
 	void _store_vector(const vec<T>& v) {
 		if (conf.read_index)
@@ -105,7 +109,7 @@ struct gpu_antitopo_engine : public ann_engine<T, gpu_antitopo_engine<T>> {
 		if (!graph)
 			throw std::runtime_error("gpu_antitopo_engine: query before build()");
 		if (!ef_search.has_value())
-			ef_search = k * conf.ef_search_mult;  // :858-859
+			set_ef_search(k * conf.ef_search_mult);  // :858-859
 		std::vector<uint32_t> dc(m);
 		int rc = expann_graph_search(graph, queries, m, k, ef_search.value(),
 		                             conf.use_compression ? 1 : 0, ids, dists, dc.data());

@@ -107,7 +107,10 @@ int expann_search_device(expann_index* h, const void* d_queries, size_t m, size_
  * sync: EXPANN_OK, or EXPANN_ERR_OVERFLOW when one of them would have needed the synchronous
  * retry (overflowed candidate lists, queries outside the fp16 range of the index): its results
  * are then invalid and the caller repeats it with "async_search" = 0.  At most 256 searches may
- * be outstanding (further ones wait by themselves). */
+ * be outstanding (further ones wait by themselves).
+ * ONE stream at a time: all searches of a handle share one workspace, so a search enqueued on a
+ * different stream than the outstanding deferred ones first waits (on the host) until those have
+ * drained; deferred searches overlap with each other only in stream order. */
 int expann_sync(expann_index* h);
 
 /* k-way merge of per-shard results after an all-gather (RCCL): in_ids/in_dists are

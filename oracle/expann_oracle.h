@@ -151,6 +151,19 @@ size_t oracle_graph_query_k(oracle_graph* g, const float* q, size_t k, size_t ef
                             int use_compression, uint64_t* ids, float* dists,
                             uint64_t* n_distcomps);
 
+
+/* Test hook: a trace of priority-queue operations through the heap code the graph search above
+ * uses (libstdc++'s make_heap / push_heap / pop_heap as restated in expann_oracle_graph.c),
+ * comparator on the distance only (src/antitopo_engine.h:540-545).  Pinned against the image's real
+ * std::priority_queue by tests/golden/heap_ref.json (oracle/ref/heap_ref.cpp).  ops[i]: 1 = push
+ * (op_d[i], op_id[i]), 0 = pop.  out_*[0] = state after construction from the init range,
+ * out_*[i + 1] = state after op i; the drain arrays need n_init + n_ops slots.  Returns the
+ * number of drained elements. */
+size_t oracle_heap_trace(int max_heap, size_t n_init, const float* init_d, const uint64_t* init_id,
+                         size_t n_ops, const int* ops, const float* op_d, const uint64_t* op_id,
+                         uint64_t* out_size, float* out_top_d, uint64_t* out_top_id, float* drain_d,
+                         uint64_t* drain_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,63 @@ static void pq_pop(pq_t* h) {
 	h->n--;
 }
 
+static void pq_make(pq_t* h) { /* std::__make_heap (priority_queue's range constructor, :551-558) */
+	const size_t len = h->n;
+	if (len < 2)
+		return;
+	for (size_t parent = (len - 2) / 2;; --parent) {
+		md_t value = h->v[parent];
+		pq_adjust(h, parent, len, value);
+		if (parent == 0)
+			break;
+	}
+}
+
+/* Test hook: run a trace of queue operations through pq_* (the heap code search_bottom uses) so
+ * that tests/test_oracle.py can compare it with the same trace run through the image's real
+ * libstdc++ (tests/golden/heap_ref.json, oracle/ref/heap_ref.cpp).  ops[i] 1 = push (op_d[i],
+ * op_id[i]), 0 = pop.  Entry 0 of the out_* arrays is the state after construction from the
+ * init range, entry i + 1 the state after op i (size 0: top fields 0).  Returns the drain length. */
+size_t oracle_heap_trace(int max_heap, size_t n_init, const float* init_d, const uint64_t* init_id,
+                         size_t n_ops, const int* ops, const float* op_d, const uint64_t* op_id,
+                         uint64_t* out_size, float* out_top_d, uint64_t* out_top_id, float* drain_d,
+                         uint64_t* drain_id) {
+	pq_t h;
+	pq_init(&h, max_heap);
+	for (size_t i = 0; i < n_init; ++i) {
+		if (h.n == h.cap) {
+			h.cap *= 2;
+			h.v = (md_t*)realloc(h.v, sizeof(md_t) * h.cap);
+		}
+		h.v[h.n].d = init_d[i];
+		h.v[h.n].id = init_id[i];
+		h.n++;
+	}
+	pq_make(&h);
+	for (size_t i = 0;; ++i) {
+		out_size[i] = h.n;
+		out_top_d[i] = h.n ? h.v[0].d : 0.0f;
+		out_top_id[i] = h.n ? h.v[0].id : 0;
+		if (i == n_ops)
+			break;
+		if (ops[i] == 1) {
+			md_t e = {op_d[i], op_id[i]};
+			pq_push(&h, e);
+		} else if (h.n) {
+			pq_pop(&h);
+		}
+	}
+	size_t nd = 0;
+	while (h.n) {
+		drain_d[nd] = h.v[0].d;
+		drain_id[nd] = h.v[0].id;
+		++nd;
+		pq_pop(&h);
+	}
+	free(h.v);
+	return nd;
+}
+
 /* src/antitopo_engine.h:25-37 (DIM % 128 == 0 -> src/distance.h:86-111) */
 static inline float g_dist2(const oracle_graph* g, const float* a, const float* b) {
 	return oracle_l2_f32(a, b, g->dim);

@@ -97,6 +97,9 @@ def _sig(lib):
     lib.oracle_graph_query_k.restype = C.c_size_t
     lib.oracle_graph_query_k.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_heap_trace.restype = C.c_size_t
+    lib.oracle_heap_trace.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t] + \
+        [C.c_void_p] * 8
     lib.oracle_recall.restype = C.c_double
     lib.oracle_recall.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
     return lib
@@ -250,6 +253,32 @@ def ref_topk_run(k, dists, ids, discard_goal=-1):
     return dict(is_good=is_good, size_after=size_after, worst_after=worst_after,
                 worst_val_after=worst_val_after, at_capacity_after=at_cap,
                 out_ids=out_ids[:cnt], out_dists=out_d[:cnt])
+
+
+def heap_trace(max_heap, init, ops, fn=None):
+    """Run a queue trace through `fn` (default: the oracle's pq_* via oracle_heap_trace; any C
+    function of the same signature, e.g. the std_heap hook of tests/native/).  init: [(d, id)],
+    ops: [(1, d, id) | (0, 0, 0)].  Returns (states [(size, top_d_bits, top_id)], drain
+    [(d_bits, id)]) in the format of tests/golden/heap_ref.json."""
+    fn = fn or lib().oracle_heap_trace
+    ini_d = np.array([x[0] for x in init], dtype=np.float32)
+    ini_id = np.array([x[1] for x in init], dtype=np.uint64)
+    op_k = np.array([x[0] for x in ops], dtype=np.int32)
+    op_d = np.array([x[1] for x in ops], dtype=np.float32)
+    op_id = np.array([x[2] for x in ops], dtype=np.uint64)
+    n_ops = len(ops)
+    size = np.zeros(n_ops + 1, dtype=np.uint64)
+    top_d = np.zeros(n_ops + 1, dtype=np.float32)
+    top_id = np.zeros(n_ops + 1, dtype=np.uint64)
+    dr_d = np.zeros(len(init) + n_ops + 1, dtype=np.float32)
+    dr_id = np.zeros(len(init) + n_ops + 1, dtype=np.uint64)
+    nd = fn(int(max_heap), len(init), _ptr(ini_d), _ptr(ini_id), n_ops, _ptr(op_k), _ptr(op_d),
+            _ptr(op_id), _ptr(size), _ptr(top_d), _ptr(top_id), _ptr(dr_d), _ptr(dr_id))
+    tb = top_d.view(np.uint32)
+    states = [(int(size[i]), int(tb[i]) if size[i] else 0, int(top_id[i]) if size[i] else 0)
+              for i in range(n_ops + 1)]
+    drain = [(int(dr_d.view(np.uint32)[i]), int(dr_id[i])) for i in range(nd)]
+    return states, drain
 
 
 class Graph:

@@ -23,18 +23,3 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _torch_gpu_first(request):
-    """Tests that share the process between torch and libexpann_hip: let torch initialise its HIP
-    context before the library creates streams (late torch initialisation after heavy use of the
-    library was observed to report 'No HIP GPUs are available' on the GPU box)."""
-    if any(item.get_closest_marker("gpu") for item in request.session.items):
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:
-            pass
-    yield

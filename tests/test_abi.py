@@ -73,3 +73,56 @@ def test_product_never_imports_the_oracle():
         if os.path.isfile(p) and re.search(r"oracle", open(p).read()):
             bad.append(p)
     assert not bad, bad
+
+
+_ORDER_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r})
+from expann_amd import _lib
+L = _lib.load()                       # the library FIRST ...
+{use}
+import torch                          # ... torch second
+mapped = _lib.hip_runtimes_mapped()
+assert len(mapped) == 1, mapped       # one HIP runtime in the process, not two
+{after}
+print("ok", mapped[0])
+"""
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """Round 1 observed 'No HIP GPUs are available' when torch initialised after the library had
+    been used.  Cause: torch's wheels bundle their own libamdhip64.so; loaded second it is mapped
+    as a SECOND runtime next to /opt/rocm's (expann_amd/_lib.py::_one_hip_runtime).  The loader
+    mechanics need no GPU to check: library first, torch second -> exactly one runtime mapped."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    out = subprocess.run([sys.executable, "-c", _ORDER_SCRIPT.format(root=ROOT, use="", after="")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_torch_initialises_after_heavy_use_of_the_library():
+    """The round-1 scenario itself, on the GPU: engines created, searched and destroyed through the
+    library first; torch's HIP context comes up afterwards in the same process and both keep working."""
+    import subprocess
+    import sys
+    use = ("import numpy as np\n"
+           "from expann_amd import GpuBruteForceEngine\n"
+           "rng = np.random.RandomState(0)\n"
+           "base = rng.standard_normal((6000, 64)).astype(np.float32)\n"
+           "q = rng.standard_normal((40, 64)).astype(np.float32)\n"
+           "first = None\n"
+           "for i in range(40):\n"
+           "    e = GpuBruteForceEngine(64, 'l2'); e.store_many_vectors(base); e.build()\n"
+           "    ids, _ = e.query_k_batch(q, 10); e.close()\n"
+           "    first = ids if first is None else first\n"
+           "    assert (ids == first).all()\n")
+    after = ("assert torch.cuda.is_available()\n"
+             "x = torch.randn(1000, 64, device='cuda'); assert float((x * x).sum()) > 0\n"
+             "e = GpuBruteForceEngine(64, 'l2'); e.store_many_vectors(base); e.build()\n"
+             "ids, _ = e.query_k_batch(q, 10); e.close(); assert (ids == first).all()\n")
+    out = subprocess.run([sys.executable, "-c", _ORDER_SCRIPT.format(root=ROOT, use=use, after=after)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]

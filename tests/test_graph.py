@@ -72,6 +72,40 @@ def test_gpu_traversal_matches_oracle(tmp_path, oracle, data, d):
             assert np.array_equal(dc.astype(np.uint64), odc), (comp, ef)
 
 
+def _sift_like(rng, n, d, frac=False):
+    x = np.clip(np.round(np.abs(rng.standard_normal((n, d))) * 40.0), 0, 255).astype(np.float32)
+    if frac:  # fractional parts: the uint8 path truncates the query (antitopo_engine.h:726-737)
+        x = np.minimum(255.5, x + rng.uniform(0, 0.99, size=x.shape)).astype(np.float32)
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prune_overflow", [0, 1])
+def test_c4_config_traversal_matches_oracle(tmp_path, oracle, prune_overflow):
+    """The reference's own sweep configuration (src/bench_runner.h:133-162): M = 60, M0 = 120,
+    ef_construction = 480, prune_overflow in {0, 1}, both compression modes, ef_search = k * {1..6}
+    -- on a 3000-row SIFT-like index (the serial host build is the reference's, ~10 ms per row).
+    Bottom-layer lists longer than one wavefront (deg > 64, graph_search.hpp's neighbour loop)
+    occur here for the first time under the checker."""
+    from graph_helpers import build_engines, check_against_oracle, read_index_degrees
+    rng = np.random.RandomState(60 + prune_overflow)
+    n, d, m, k = 3000, 128, 64, 10
+    base = _sift_like(rng, n, d)
+    q = _sift_like(rng, m, d, frac=True)
+    engs, idx = build_engines(base, tmp_path, M=60, ef_construction=480, prune_overflow=prune_overflow)
+    hdr, deg0 = read_index_degrees(idx)
+    assert (hdr["M"], hdr["M0"], hdr["ef_construction"], hdr["prune_overflow"]) == (60, 120, 480, prune_overflow)
+    assert deg0.max() > 64 and deg0.max() <= 120, deg0.max()
+    g = check_against_oracle(oracle, engs, idx, q, k, efs=[k * mult for mult in (1, 2, 3, 4, 5, 6)])
+    # and it is a usable index: recall@10 at ef = 60 against the exact answer
+    gt, _ = oracle.brute_force(g.vectors(), q, k)
+    engs[False].set_ef_search(60)
+    ids, _ = engs[False].query_many(q, k)
+    assert oracle.recall(ids, gt) > 0.9
+    for e in engs.values():
+        e.close()
+
+
 @pytest.mark.gpu
 def test_python_module_surface(tmp_path, oracle):
     """The pyrunner.cpp surface (AntitopoEngine): zero-padding to the engine dimension,
