@@ -4,15 +4,20 @@
 A "step" is one pass of the hot path over one batch: the brute-force k-NN search of M
 queries against the N-row fp32 base (config C2: N=1M, d=128, M=10k, k=10, L2), inputs
 resident in HBM.  With --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) the
-base is sharded by contiguous row ranges (strong scaling: total N and total queries fixed).
-Default rank grid: 2 row shards x (N/2) query groups (expann_amd/sharded.py): every rank scans
-its rows for its query slice, the per-shard top-k are all-gathered over RCCL inside the query
-group and merged, and the merged slices are all-gathered so that every rank holds the full
-result.  --row-shards N gives pure row sharding.
+base is sharded by contiguous row ranges (strong scaling: total N and total queries fixed):
+pure row sharding, as BASELINE's north_star words it -- rank r holds rows [r*ceil(N/G), ...), every
+rank scans its rows for ALL queries, the per-shard top-k are exchanged with ONE RCCL all-gather and
+merged, all behind the C ABI (expann_sharded_*, csrc/expann_sharded.hip; torch.distributed only
+hands out the RCCL unique id and provides the barriers around the timed region).
+--row-shards R < G selects the hybrid grid of expann_amd/sharded.py instead (R row shards x G/R
+query groups, exchanged through torch.distributed), --exchange torch the same collectives through
+torch.distributed.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, timed with HIP events on its stream inside the library) and `cpu_baseline` (the CPU
-oracle timed on this box's host cores on a bounded sample; N=1 only).
+kernel, timed with HIP events on its stream inside the library), `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample; N=1 only) and the bench's own proof of
+its claim: `recall_measured`, `verified_queries`, `bit_exact` (the GPU result of the timed step
+against the oracle on a sample of the step's queries; a mismatch exits non-zero).
 """
 import argparse
 import json
@@ -50,8 +55,16 @@ def parse():
                          "--n rows, built on the host CPU first)")
     ap.add_argument("--query-tile", type=int, default=0)
     ap.add_argument("--row-shards", type=int, default=0,
-                    help="row shards of the rank grid (default: 2 when --gpus is even, queries split "
-                         "over the remaining factor; --row-shards N = pure row sharding)")
+                    help="row shards of the rank grid (default: --gpus = pure row sharding, every rank "
+                         "searches every query; R < --gpus: R row shards x gpus/R query groups)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
+                    help="native: RCCL all-gather + merge behind the C ABI (expann_sharded_*; default for "
+                         "pure row sharding); torch: the same exchange through torch.distributed "
+                         "(always for the hybrid grid and the one-GPU rehearsal)")
+    ap.add_argument("--verify-queries", type=int, default=0,
+                    help="queries of the step checked against the CPU oracle when no cpu_baseline leg "
+                         "runs (G > 1 or --no-cpu-baseline); default 8, 0 with --no-verify")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed loop rank 0 checks the sharded result bit for bit against an "
@@ -119,21 +132,39 @@ def cpu_baseline(base_host, queries_host, k, budget_s, metric_name="METRIC_L2_F3
     # bound, so more threads than memory channels can be slower: try a few pool sizes and
     # report the best one (cores = the threads actually used for the reported value).
     best = (0.0, 1, 0)
+    checked = None      # oracle (ids, dists) of the longest prefix of the step's queries it scanned
     cands = sorted({min(avail, c) for c in (16, 32, 64, avail)})
     per = budget_s * 0.7 / len(cands)
     for c in cands:
         nq = int(min(len(queries_host), max(c, per * qps1 * min(c, 16) * 0.5)))
         nq = max(c, (nq // c) * c)
         t0 = time.perf_counter()
-        oc.brute_force(base_host, queries_host[:nq], k, getattr(oc, metric_name), c, _lib_override=lib)
+        res = oc.brute_force(base_host, queries_host[:nq], k, getattr(oc, metric_name), c, _lib_override=lib)
         q = nq / (time.perf_counter() - t0)
         if q > best[0]:
             best = (q, c, nq)
+        if checked is None or nq > checked[0].shape[0]:
+            checked = res
     qps_all, cores, nall = best
     return {"value": round(qps_all, 2), "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"{nall} of the step's queries x all {base_host.shape[0]} rows on {cores} "
                       f"threads ({flags}); 1 thread: {qps1:.2f} queries/s over {n1} queries",
-            "single_thread_value": round(qps1, 2)}
+            "single_thread_value": round(qps1, 2)}, checked
+
+
+def oracle_check(oracle_ids, oracle_d, gpu_ids, gpu_d):
+    """The bench's proof of its claim (the reference computes recall inside its harness,
+    src/basic_bench.h:106-121,143): GPU ids / distance bits of the first rows of the step's result
+    against the oracle's for the same queries.  -> (recall, n_queries, bit_exact)"""
+    import numpy as np
+    nq, k = oracle_ids.shape
+    g_ids = np.ascontiguousarray(gpu_ids[:nq]).view(np.uint64)
+    g_d = np.ascontiguousarray(gpu_d[:nq])
+    found = sum(len(np.intersect1d(g_ids[i], oracle_ids[i])) for i in range(nq))
+    valid = int((oracle_ids != np.uint64(2 ** 64 - 1)).sum())
+    bit_exact = bool(np.array_equal(g_ids, oracle_ids)) and \
+        bool(np.array_equal(g_d.view(np.uint32), oracle_d.view(np.uint32)))
+    return found / max(1, valid), nq, bit_exact
 
 
 def profiled_traffic(kernel_name):
@@ -228,14 +259,16 @@ def main():
     a = parse()
     if a.workload == "c4":
         return bench_c4(a)
+    import numpy as np
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = bool(os.environ.get("EXPANN_BENCH_REHEARSAL"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("EXPANN_BENCH_REHEARSAL"):
+        if rehearsal:
             # rehearsal of the rank grid on a box with fewer GPUs than ranks: gloo, ranks share GPUs
             local_rank = local_rank % torch.cuda.device_count()
             dist.init_process_group("gloo")
@@ -245,23 +278,42 @@ def main():
     G = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from expann_amd import GpuBruteForceEngine, merge_topk_device
+    from expann_amd import GpuBruteForceEngine, ShardedBruteForceEngine
 
-    # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
-    from expann_amd.sharded import shard_range, shard_grid
-    R, Q = shard_grid(G, a.row_shards or None)       # rank = query group x row shard
+    # rank grid: pure row sharding by default (every rank searches every query); R < G = hybrid grid
+    from expann_amd.sharded import shard_range, shard_grid, ceil_shard_range
+    R, Q = shard_grid(G, a.row_shards or G)       # rank = query group x row shard
+    native = G > 1 and R == G and not rehearsal and a.exchange in ("auto", "native")
+    if a.exchange == "native" and G > 1 and not native:
+        raise SystemExit("--exchange native needs pure row sharding on one GPU per rank")
     row_idx, qgroup = rank % R, rank // R
-    lo, hi = shard_range(a.n, row_idx, R)
+    # rank r holds rows [r * ceil(N/R), min(N, (r+1) * ceil(N/R)))
+    lo, hi = ceil_shard_range(a.n, row_idx, R)
     q_lo, q_hi = shard_range(a.m, qgroup, Q)
     m_local, pad = q_hi - q_lo, (a.m + Q - 1) // Q
+
+    # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
     g = torch.Generator(device=dev)
-    g.manual_seed(1234 + row_idx)
+
+    def make_rows(r_idx):
+        r_lo, r_hi = ceil_shard_range(a.n, r_idx, R)
+        g.manual_seed(1234 + r_idx)
+        if a.dtype == "f32":
+            b = torch.randn(r_hi - r_lo, a.d, device=dev, dtype=torch.float32, generator=g)
+            if a.sift_like:
+                b = b.abs_().mul_(40).round_().clamp_(0, 255)
+            return b
+        if a.dtype == "i8":   # int8 uniform in [-127, 127]
+            return torch.randint(-127, 128, (r_hi - r_lo, a.d), device=dev, dtype=torch.int8, generator=g)
+        # SURVEY 8d C4 stand-in: clamp(round(|N(0,1)|*40), 0, 255)
+        return torch.randn(r_hi - r_lo, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
+            .clamp_(0, 255).to(torch.uint8)
+
+    base = make_rows(row_idx)
+    g.manual_seed(4321)
     if a.dtype == "f32":
-        base = torch.randn(hi - lo, a.d, device=dev, dtype=torch.float32, generator=g)
-        g.manual_seed(4321)
         queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
         if a.sift_like:
-            base = base.abs_().mul_(40).round_().clamp_(0, 255)
             queries = queries.abs_().mul_(40).round_().clamp_(0, 255)
         if a.clustered and G == 1:
             # rows sorted by cluster: centres N(0, 1), members centre + 0.3 N(0, 1); queries near centres
@@ -270,35 +322,30 @@ def main():
             base = base.mul_(0.3).add_(centres.repeat_interleave(per, 0)[:a.n])
             pick = torch.randint(0, a.clustered, (a.m,), device=dev, generator=g)
             queries = queries.mul_(0.3).add_(centres[pick])
-    elif a.dtype == "i8":   # int8 uniform in [-127, 127]
-        base = torch.randint(-127, 128, (hi - lo, a.d), device=dev, dtype=torch.int8, generator=g)
-        g.manual_seed(4321)
+    elif a.dtype == "i8":
         queries = torch.randint(-127, 128, (a.m, a.d), device=dev, dtype=torch.int8, generator=g)
-    else:                   # SURVEY 8d C4 stand-in: clamp(round(|N(0,1)|*40), 0, 255)
-        base = torch.randn(hi - lo, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
-            .clamp_(0, 255).to(torch.uint8)
-        g.manual_seed(4321)
+    else:
         queries = torch.randn(a.m, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
             .clamp_(0, 255).to(torch.float32)
 
-    eng = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
-    eng.set_base_device(base.data_ptr(), hi - lo, lo)
-    if a.query_tile:
-        eng.set_option("query_tile", a.query_tile)
-    if a.scan_kernel:
-        eng.set_option("scan_kernel", a.scan_kernel)
-    if a.debug:
-        eng.set_option("debug", a.debug)
-    if a.sample_ratio:
-        eng.set_option("sample_ratio", a.sample_ratio)
-    if a.sample_frac:
-        eng.set_option("sample_frac", a.sample_frac)
-    if a.scan_chunks:
-        eng.set_option("scan_chunks", a.scan_chunks)
+    if native:
+        # one process per GPU, the exchange behind the C ABI: rank 0's RCCL unique id travels over
+        # torch.distributed, ncclCommInitRank / ncclAllGather / merge run inside libexpann_hip
+        box = [ShardedBruteForceEngine.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
+                                      unique_id=box[0])
+        eng.set_shard_device(0, base.data_ptr(), hi - lo, lo)
+    else:
+        eng = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
+        eng.set_base_device(base.data_ptr(), hi - lo, lo)
+    for name, val in (("query_tile", a.query_tile), ("scan_kernel", a.scan_kernel), ("debug", a.debug),
+                      ("sample_ratio", a.sample_ratio), ("sample_frac", a.sample_frac),
+                      ("scan_chunks", a.scan_chunks), ("sample_run", a.sample_run)):
+        if val:
+            eng.set_option(name, val)
     if a.xcd_tolerance >= 0:
         eng.set_option("xcd_tolerance", a.xcd_tolerance)
-    if a.sample_run:
-        eng.set_option("sample_run", a.sample_run)
     from expann_amd.sharded import GridShardedSearch, chunk_bytes, unpack_chunk
     from expann_amd import merge_topk_strided_device
     bufs = {}
@@ -308,7 +355,7 @@ def main():
     torch.cuda.synchronize()
     work_stream = torch.cuda.Stream(device=dev)
     stream = work_stream.cuda_stream
-    use_async = not a.sync_search and not os.environ.get("EXPANN_BENCH_REHEARSAL")
+    use_async = not a.sync_search
     if use_async:
         # deferred check: a search is enqueued without a host wait, so the next kernels / the RCCL
         # exchange are already queued when it ends; expann_sync validates all steps at the end
@@ -333,11 +380,20 @@ def main():
         merge_topk_strided_device(local_rank, gp, gp + rows * k * 8, cb // 8, cb // 4, n_lists, rows, k,
                                   op, op + rows * k * 8, stream)
 
-    ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
+    if native:
+        out_ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
+        out_d = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
 
-    def step():
-        with torch.cuda.stream(work_stream):
-            ss.search(queries, a.k)
+        def step():
+            # local scan, ncclAllGather, merge: all enqueued on `stream` by the library
+            eng.search_device(queries.data_ptr(), a.m, a.k, out_ids.data_ptr(), out_d.data_ptr(), stream)
+            return out_ids, out_d
+    else:
+        ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
+
+        def step():
+            with torch.cuda.stream(work_stream):
+                return ss.search(queries, a.k)
 
     def timed(n_steps):
         """(seconds, ok): ok is False when a deferred search of the loop needed the synchronous
@@ -366,7 +422,7 @@ def main():
         return dt, ok
 
     # one-time lazy initialisation outside any count: derived copies of the index (fp16 / uint8),
-    # workspace allocation and -- with G > 1 -- the communicators of the two process groups
+    # workspace allocation and -- with G > 1 -- the communicators
     step()
     if use_async:
         eng.sync()
@@ -389,33 +445,36 @@ def main():
         elapsed = float(t.item())
     prof = eng.get_profile()
     eng.set_profiling(False)
-    if a.verify and a.dtype == "f32":
-        with torch.cuda.stream(work_stream):
-            got_ids, got_d = ss.search(queries, a.k)
-        if use_async:
-            eng.sync()
-        torch.cuda.synchronize()
+    # one more step, outside the timed region, whose result the checks below look at (it is the
+    # same search on the same inputs as every timed step)
+    got_ids, got_d = step()
+    if use_async:
+        eng.sync()
+    torch.cuda.synchronize()
+    got_ids, got_d = got_ids[:a.m], got_d[:a.m]
+
+    def whole_base():
+        return base if R == 1 else torch.cat([base if r == row_idx else make_rows(r) for r in range(R)], 0)
+
+    if a.verify and G > 1:
         if rank == 0:
-            parts = []
-            for r in range(R):
-                r_lo, r_hi = shard_range(a.n, r, R)
-                g.manual_seed(1234 + r)
-                parts.append(torch.randn(r_hi - r_lo, a.d, device=dev, dtype=torch.float32, generator=g))
-            whole = torch.cat(parts, 0)
+            whole = whole_base()
             ref = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
             ref.set_base_device(whole.data_ptr(), a.n, 0)
             ref_ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
             ref_d = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
             ref.search_device(queries.data_ptr(), a.m, a.k, ref_ids.data_ptr(), ref_d.data_ptr(), stream)
             torch.cuda.synchronize()
-            same = bool(torch.equal(got_ids[:a.m], ref_ids)) and \
-                bool(torch.equal(got_d[:a.m].view(torch.int32), ref_d.view(torch.int32)))
+            same = bool(torch.equal(got_ids, ref_ids)) and \
+                bool(torch.equal(got_d.view(torch.int32), ref_d.view(torch.int32)))
             print(f"verify: sharded rows/{R} x queries/{Q} result "
                   f"{'IDENTICAL to' if same else 'DIFFERS from'} the unsharded search", file=sys.stderr)
             ref.close()
+            del whole
             if not same:
                 sys.exit(3)
 
+    rc = 0
     if rank == 0:
         ms_per_step = elapsed * 1e3 / a.steps
         qps = a.m * a.steps / elapsed
@@ -489,6 +548,15 @@ def main():
             "candidates_per_query": round(prof["candidates"] / m_local, 1)})
         desc = {"f32": "fp32", "i8": "int8", "u8": "uint8"}[a.dtype]
         shape = f"{a.n // 1_000_000}M" if a.n % 1_000_000 == 0 else str(a.n)
+        deferred = int(prof.get("deferred_searches", 0))
+        if use_async and deferred >= launches:
+            host_sync = ("deferred: searches are enqueued back to back, one expann_sync validates all K "
+                         "steps inside the timed region")
+        elif use_async and deferred:
+            host_sync = f"mixed: {deferred} of {int(launches)} timed searches deferred their check"
+        else:
+            host_sync = "per step" + (" (this path checks its flags at once: exact-uint8 shortcut / retry)"
+                                      if use_async else "")
         out = {"metric": f"queries/sec at recall@{a.k}=1.0 (exact brute force), {shape}xd{a.d} {desc}, k={a.k}",
                "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -497,28 +565,55 @@ def main():
                                       f"{a.m} batched queries, k={a.k} (BASELINE "
                                       f"{'configs[1]' if a.workload == 'c2' else 'configs[4]'})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
-                          "host_sync": ("deferred: searches are enqueued back to back, one expann_sync "
-                                        "validates all K steps inside the timed region") if use_async
-                          else "per step",
-                          "sharding": (f"rows/{R} x queries/{Q} (rank 0 scans {n_local} rows for {m_local} "
-                                       f"queries; roofline figures are rank 0's launch)")
-                          if G > 1 else "none"},
+                          "host_sync": host_sync,
+                          "sharding": (f"rows/{R} x queries/{Q}: rank r scans rows [r*ceil(N/{R}), ...) for "
+                                       f"{'all' if Q == 1 else 'its slice of the'} queries; exchange = "
+                                       f"{'RCCL all-gather + merge behind the C ABI (expann_sharded_*)' if native else 'torch.distributed all_gather + expann_merge_topk'}"
+                                       f"; rank 0 scans {n_local} rows for {m_local} queries, roofline figures "
+                                       f"are rank 0's launch") if G > 1 else "none"},
                "roofline": roofline}
+        # ---- the bench proves its own claim: GPU result vs the CPU oracle -----------------------
+        checked = None
+        mname = {("f32", "l2"): "METRIC_L2_F32", ("f32", "ip"): "METRIC_IP_F32",
+                 ("i8", "l2"): "METRIC_L2_I8", ("i8", "ip"): "METRIC_IP_I8",
+                 ("u8", "l2"): "METRIC_L2_U8"}[(a.dtype, a.metric)]
+        base_host = queries_host = None
         if G == 1 and not a.no_cpu_baseline:
             try:
-                mname = {("f32", "l2"): "METRIC_L2_F32", ("f32", "ip"): "METRIC_IP_F32",
-                         ("i8", "l2"): "METRIC_L2_I8", ("i8", "ip"): "METRIC_IP_I8",
-                         ("u8", "l2"): "METRIC_L2_U8"}[(a.dtype, a.metric)]
-                out["cpu_baseline"] = cpu_baseline(base.cpu().numpy(), queries.cpu().numpy(), a.k,
-                                                   a.cpu_seconds, mname)
+                base_host, queries_host = base.cpu().numpy(), queries.cpu().numpy()
+                out["cpu_baseline"], checked = cpu_baseline(base_host, queries_host, a.k, a.cpu_seconds, mname)
             except Exception as e:  # the baseline is a reported extra, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
                                        "kind": "port", "sample": f"failed: {e}"}
+        if checked is None and not a.no_verify:
+            nv = a.verify_queries or 8
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_ctypes as oc
+                if base_host is None:
+                    base_host, queries_host = whole_base().cpu().numpy(), queries.cpu().numpy()
+                checked = oc.brute_force(base_host, queries_host[:nv], a.k, getattr(oc, mname),
+                                         min(nv, os.cpu_count() or 1))
+            except Exception as e:
+                out["verify_error"] = str(e)
+        if checked is not None and not a.no_verify:
+            recall, nq, exact = oracle_check(checked[0], checked[1], got_ids.cpu().numpy(), got_d.cpu().numpy())
+            out["recall_measured"] = round(recall, 6)
+            out["verified_queries"] = nq
+            out["bit_exact"] = exact
+            out["verified_against"] = ("oracle/expann_oracle.c (CPU restatement of src/brute_force_engine.h:28-46 "
+                                       "+ src/distance.h), same inputs, ids and distance bits")
+            if not exact or recall != 1.0:
+                print(f"bench: GPU result DIFFERS from the oracle on {nq} checked queries "
+                      f"(recall {recall:.6f}, bit_exact {exact})", file=sys.stderr)
+                rc = 4
         print(json.dumps(out), flush=True)
     eng.close()
     if G > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,8 @@ Package contents: csrc/ (hand-written HIP kernels + the C ABI of include/expann_
 into libexpann_hip.so) and the host-side mirror of the reference's engine interface.
 """
 from . import _lib  # noqa: F401
-from .engine import GpuBruteForceEngine, merge_topk_device, merge_topk_strided_device  # noqa: F401
+from .engine import (GpuBruteForceEngine, ShardedBruteForceEngine, merge_topk_device,  # noqa: F401
+                     merge_topk_strided_device)
 from .pyrunner import AntitopoEngine  # noqa: F401
 
-__all__ = ["GpuBruteForceEngine", "merge_topk_device", "merge_topk_strided_device", "AntitopoEngine"]
+__all__ = ["GpuBruteForceEngine", "ShardedBruteForceEngine", "merge_topk_device", "merge_topk_strided_device", "AntitopoEngine"]

@@ -25,6 +25,12 @@ ABI_SYMBOLS = [
     "expann_antitopo_store", "expann_antitopo_build", "expann_antitopo_set_ef_search",
     "expann_antitopo_query", "expann_antitopo_save", "expann_antitopo_load",
     "expann_antitopo_size", "expann_antitopo_num_distcomps",
+    "expann_sharded_create", "expann_sharded_unique_id", "expann_sharded_create_rank",
+    "expann_sharded_destroy", "expann_sharded_last_error", "expann_sharded_add", "expann_sharded_build",
+    "expann_sharded_set_shard_device", "expann_sharded_size", "expann_sharded_shards",
+    "expann_sharded_exchange", "expann_sharded_search", "expann_sharded_search_device",
+    "expann_sharded_sync", "expann_sharded_set_option", "expann_sharded_set_profiling",
+    "expann_sharded_get_profile",
 ]
 
 
@@ -32,7 +38,7 @@ class Profile(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_ms", C.c_double), ("scan_rows", C.c_uint64),
                 ("scan_query_tiles", C.c_uint64), ("query_tile", C.c_uint32),
                 ("levels", C.c_uint32), ("candidates", C.c_uint64), ("retries", C.c_uint64),
-                ("scan_kernel", C.c_char * 64)]
+                ("scan_kernel", C.c_char * 64), ("deferred_searches", C.c_uint64)]
 
 
 class ExpannError(RuntimeError):
@@ -156,6 +162,41 @@ def load():
     L.expann_antitopo_size.argtypes = [vp]
     L.expann_antitopo_num_distcomps.restype = u64
     L.expann_antitopo_num_distcomps.argtypes = [vp]
+    L.expann_sharded_create.restype = C.c_int
+    L.expann_sharded_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.expann_sharded_unique_id.restype = C.c_int
+    L.expann_sharded_unique_id.argtypes = [vp]
+    L.expann_sharded_create_rank.restype = C.c_int
+    L.expann_sharded_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                             C.POINTER(vp)]
+    L.expann_sharded_destroy.restype = None
+    L.expann_sharded_destroy.argtypes = [vp]
+    L.expann_sharded_last_error.restype = C.c_char_p
+    L.expann_sharded_last_error.argtypes = [vp]
+    L.expann_sharded_add.restype = C.c_int
+    L.expann_sharded_add.argtypes = [vp, vp, sz]
+    L.expann_sharded_build.restype = C.c_int
+    L.expann_sharded_build.argtypes = [vp]
+    L.expann_sharded_set_shard_device.restype = C.c_int
+    L.expann_sharded_set_shard_device.argtypes = [vp, C.c_int, vp, sz, u64]
+    L.expann_sharded_size.restype = sz
+    L.expann_sharded_size.argtypes = [vp]
+    L.expann_sharded_shards.restype = C.c_int
+    L.expann_sharded_shards.argtypes = [vp]
+    L.expann_sharded_exchange.restype = C.c_int
+    L.expann_sharded_exchange.argtypes = [vp]
+    L.expann_sharded_search.restype = C.c_int
+    L.expann_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.expann_sharded_search_device.restype = C.c_int
+    L.expann_sharded_search_device.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.expann_sharded_sync.restype = C.c_int
+    L.expann_sharded_sync.argtypes = [vp]
+    L.expann_sharded_set_option.restype = C.c_int
+    L.expann_sharded_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.expann_sharded_set_profiling.restype = C.c_int
+    L.expann_sharded_set_profiling.argtypes = [vp, C.c_int]
+    L.expann_sharded_get_profile.restype = C.c_int
+    L.expann_sharded_get_profile.argtypes = [vp, C.c_int, C.POINTER(Profile)]
     L.expann_set_profiling.restype = C.c_int
     L.expann_set_profiling.argtypes = [vp, C.c_int]
     L.expann_get_profile.restype = C.c_int

@@ -632,6 +632,7 @@ bool defer_flags(expann_index* h, hipStream_t st, int attempt) {
 	h->h_flag_ring[8 * h->async_pending + 7] = h->dtype == EXPANN_DTYPE_U8 ? 1u : 0u;
 	h->async_pending++;
 	h->async_stream = st;
+	h->prof.deferred_searches++;
 	return true;
 }
 
@@ -1019,6 +1020,7 @@ int absorb_shadow_profile(expann_index* h) {
 	h->prof.scan_rows += sh->prof.scan_rows;
 	h->prof.scan_query_tiles += sh->prof.scan_query_tiles;
 	h->prof.retries += sh->prof.retries;
+	h->prof.deferred_searches += sh->prof.deferred_searches;
 	h->prof.query_tile = sh->prof.query_tile;
 	h->prof.levels = sh->prof.levels;
 	h->prof.candidates = sh->prof.candidates;

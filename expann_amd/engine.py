@@ -128,6 +128,129 @@ class GpuBruteForceEngine:
             pass
 
 
+class ShardedBruteForceEngine:
+    """Row-sharded exact k-NN over several GPUs behind ONE handle (expann_sharded_*): rows cut into
+    contiguous ranges, one RCCL all-gather of the per-shard top-k, merge in the reference's (score, id)
+    order -- results bit-identical to GpuBruteForceEngine.  Two forms:
+      ShardedBruteForceEngine(dim, devices=[0, 1, ...])                  in-process, host buffers
+      ShardedBruteForceEngine(dim, device=d, rank=r, world=G, unique_id=b)   one process per GPU"""
+
+    def __init__(self, dim, metric="l2", dtype="f32", devices=None, device=0, rank=None, world=None,
+                 unique_id=None):
+        self._L = _lib.load()
+        self.dim = int(dim)
+        self.metric = {"l2": _lib.METRIC_L2, "ip": _lib.METRIC_IP,
+                       "l2_i8_refcompat": _lib.METRIC_L2_I8_REFCOMPAT}[metric]
+        self.dtype = {"f32": _lib.DTYPE_F32, "u8": _lib.DTYPE_U8, "i8": _lib.DTYPE_I8,
+                      "i16": _lib.DTYPE_I16}[dtype]
+        h = C.c_void_p()
+        if rank is None:
+            devs = list(devices if devices is not None else [device])
+            arr = (C.c_int * len(devs))(*devs)
+            rc = self._L.expann_sharded_create(self.dim, self.dtype, self.metric, arr, len(devs), C.byref(h))
+            self.devices, self.rank, self.world = devs, None, len(devs)
+        else:
+            buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+            rc = self._L.expann_sharded_create_rank(self.dim, self.dtype, self.metric, int(device), int(rank),
+                                                    int(world), buf, C.byref(h))
+            self.devices, self.rank, self.world = [int(device)], int(rank), int(world)
+        if rc != _lib.OK:
+            raise _lib.ExpannError(rc, self._L.expann_sharded_last_error(None).decode())
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        """128 bytes for the rank form (ncclGetUniqueId); rank 0 makes it, the launcher distributes it."""
+        L = _lib.load()
+        buf = C.create_string_buffer(128)
+        rc = L.expann_sharded_unique_id(buf)
+        if rc != _lib.OK:
+            raise _lib.ExpannError(rc, L.expann_sharded_last_error(None).decode())
+        return buf.raw
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise _lib.ExpannError(rc, self._L.expann_sharded_last_error(self._h).decode())
+
+    def name(self):
+        return "GPU Brute-Force Engine, row-sharded (MI355X)"
+
+    def param_list(self):
+        return {"devices": ",".join(map(str, self.devices)), "shards": str(self.shards()),
+                "exchange": {0: "none", 1: "rccl", 2: "device copies"}[self.exchange()]}
+
+    def store_many_vectors(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=_NP_DTYPE[self.dtype])
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}]")
+        self._check(self._L.expann_sharded_add(self._h, rows.ctypes.data, rows.shape[0]))
+
+    def store_vector(self, v):
+        self.store_many_vectors(np.asarray(v).reshape(1, -1))
+
+    def build(self):
+        self._check(self._L.expann_sharded_build(self._h))
+
+    def set_shard_device(self, shard, ptr, n, id_offset):
+        self._check(self._L.expann_sharded_set_shard_device(self._h, int(shard), C.c_void_p(ptr), n, id_offset))
+
+    def query_k_batch(self, queries, k):
+        qdt = np.float32 if self.dtype in (_lib.DTYPE_F32, _lib.DTYPE_U8) else _NP_DTYPE[self.dtype]
+        queries = np.ascontiguousarray(queries, dtype=qdt)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise ValueError(f"queries must be [m, {self.dim}]")
+        m = queries.shape[0]
+        ids = np.empty((m, k), dtype=np.uint64)
+        dists = np.empty((m, k), dtype=np.float32)
+        self._check(self._L.expann_sharded_search(self._h, queries.ctypes.data, m, k, ids.ctypes.data,
+                                                  dists.ctypes.data))
+        return ids, dists
+
+    def query_k(self, v, k):
+        ids, _ = self.query_k_batch(np.asarray(v).reshape(1, -1), k)
+        row = ids[0]
+        return [int(x) for x in row[row != np.uint64(2 ** 64 - 1)]]
+
+    def search_device(self, q_ptr, m, k, ids_ptr, dists_ptr, stream=0):
+        self._check(self._L.expann_sharded_search_device(self._h, C.c_void_p(q_ptr), m, k, C.c_void_p(ids_ptr),
+                                                         C.c_void_p(dists_ptr), C.c_void_p(stream)))
+
+    def sync(self):
+        self._check(self._L.expann_sharded_sync(self._h))
+
+    def set_option(self, name, value):
+        self._check(self._L.expann_sharded_set_option(self._h, name.encode(), int(value)))
+
+    def set_profiling(self, enable=True):
+        self._check(self._L.expann_sharded_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self, shard=0):
+        p = _lib.Profile()
+        self._check(self._L.expann_sharded_get_profile(self._h, int(shard), C.byref(p)))
+        return {f: (getattr(p, f).decode() if f == "scan_kernel" else getattr(p, f))
+                for f, _ in _lib.Profile._fields_}
+
+    def size(self):
+        return self._L.expann_sharded_size(self._h)
+
+    def shards(self):
+        return self._L.expann_sharded_shards(self._h)
+
+    def exchange(self):
+        return self._L.expann_sharded_exchange(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.expann_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def merge_topk_strided_device(device, in_ids_ptr, in_dists_ptr, ids_stride, dists_stride, n_lists, m,
                               k, out_ids_ptr, out_dists_ptr, stream=0):
     """expann_merge_topk_strided_device: list g at in_ids + g*ids_stride / in_dists + g*dists_stride

@@ -7,6 +7,8 @@
 // exact brute force: src/dataset_loader.h:27-38) and prints one bench_data JSON per run
 // mode with the reference's field names (src/bench_data.h:20-28).
 //
+// --devices 0,1,...,7 runs the engine under test row-sharded over several GPUs (BASELINE configs[2]).
+//
 // Differences, all deliberate: the dimension is a run-time value (the reference bakes
 // -DDIM into the binary, CMakeLists.txt:87); the random seed is fixed (1234) instead of
 // std::random_device; Sift1M needs *.fvecs files that are not shipped (use --dataset
@@ -82,6 +84,20 @@ int main(int argc, char** argv) {
 	const std::string dataset = get("dataset", "Synthetic");
 	dense_test_dataset<float> ds;
 	const int device = std::stoi(get("device", "0"));
+	// --devices 0,1,2,...: the engine under test shards the base over these GPUs (one handle, RCCL
+	// all-gather of the per-shard top-k); the ground truth stays on --device
+	std::vector<int> devices;
+	{
+		std::stringstream ss(get("devices", ""));
+		std::string tok;
+		while (std::getline(ss, tok, ','))
+			if (!tok.empty())
+				devices.push_back(std::stoi(tok));
+	}
+	auto engine_config = [&]() {
+		return devices.size() > 1 ? gpu_brute_force_engine<float>::config(devices)
+		                          : gpu_brute_force_engine<float>::config(devices.empty() ? device : devices[0]);
+	};
 	const std::string mode = get("mode", "both");  // serial | batched | both
 	bool have_ground_truth = false;
 	if (dataset == "Sift1M") {
@@ -146,7 +162,7 @@ int main(int argc, char** argv) {
 		std::ofstream out;
 		if (cli.count("out")) out.open(cli["out"]);
 		if (mode == "serial" || mode == "both") {
-			gpu_brute_force_engine<float>::config ecfg(device);
+			gpu_brute_force_engine<float>::config ecfg = engine_config();
 			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data(eng);
 			bd.param_list["mode"] = "serial";
@@ -155,7 +171,7 @@ int main(int argc, char** argv) {
 			if (out) out << bd.to_string() << "\n";
 		}
 		if (mode == "batched" || mode == "both") {
-			gpu_brute_force_engine<float>::config ecfg(device);
+			gpu_brute_force_engine<float>::config ecfg = engine_config();
 			gpu_brute_force_engine<float> eng(ecfg);
 			bench_data bd = bench.get_benchmark_data_batched(eng);
 			bd.param_list["mode"] = "batched";

@@ -20,6 +20,13 @@ def shard_range(n, rank, world):
     return rank * n // world, (rank + 1) * n // world
 
 
+def ceil_shard_range(n, rank, world):
+    """SURVEY 8e's partition: rank r holds rows [r * ceil(n/G), min(n, (r+1) * ceil(n/G))) -- the one
+    expann_sharded_build (csrc/expann_sharded.hip) cuts too.  Trailing shards may be empty."""
+    per = (n + world - 1) // world
+    return min(n, rank * per), min(n, (rank + 1) * per)
+
+
 class ShardedSearch:
     def __init__(self, dist, world, local_search, merge, alloc_gather):
         """dist: torch.distributed (or None when world == 1);
@@ -43,13 +50,13 @@ class ShardedSearch:
 
 
 def shard_grid(world, row_shards=None):
-    """(row_shards, query_groups) of a `world`-rank job.  The base is always sharded when there is
-    more than one rank; by default into TWO row shards, the remaining factor splits
-    the queries: per-query costs (conversion, threshold pass, selection, result exchange) then
-    shrink with the group count instead of being repeated on every rank, and the all-gather of
-    per-shard top-k runs between 2 ranks.  `row_shards` = world reproduces pure row sharding."""
+    """(row_shards, query_groups) of a `world`-rank job.  Default: pure row sharding (SURVEY 8e,
+    BASELINE's north_star): `world` row shards, every rank searches every query.  With
+    row_shards = R < world the remaining factor splits the QUERIES: per-query costs (conversion,
+    threshold pass, selection, result exchange) then shrink with the group count instead of being
+    repeated on every rank, and the all-gather of per-shard top-k runs between R ranks."""
     if row_shards is None:
-        row_shards = 2 if world % 2 == 0 else world
+        row_shards = world
     if world % row_shards:
         raise ValueError(f"row_shards {row_shards} does not divide world {world}")
     return row_shards, world // row_shards

@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ann_engine.h"
@@ -27,9 +29,16 @@ struct gpu_brute_force_engine_config {
 	int device = 0;
 	int metric = EXPANN_METRIC_L2;
 	long query_tile = 0;  // 0 = auto
+	// more than one entry: the base is row-sharded over these devices behind the same engine
+	// (expann_sharded_*: contiguous row ranges, one RCCL all-gather of the per-shard top-k, merge);
+	// results are bit-identical to the single-device engine
+	std::vector<int> devices;
 	gpu_brute_force_engine_config() = default;
 	gpu_brute_force_engine_config(int _device, int _metric = EXPANN_METRIC_L2, long _query_tile = 0)
 	    : device(_device), metric(_metric), query_tile(_query_tile) {}
+	gpu_brute_force_engine_config(std::vector<int> _devices, int _metric = EXPANN_METRIC_L2, long _query_tile = 0)
+	    : device(_devices.empty() ? 0 : _devices[0]), metric(_metric), query_tile(_query_tile),
+	      devices(std::move(_devices)) {}
 };
 
 template <typename T>
@@ -37,6 +46,7 @@ struct gpu_brute_force_engine : public ann_engine<T, gpu_brute_force_engine<T>> 
 	using config = gpu_brute_force_engine_config;
 	config conf;
 	expann_index* handle = nullptr;
+	expann_sharded* sharded = nullptr;  // conf.devices.size() > 1
 	size_t dimension = 0;
 	size_t stored = 0;
 
@@ -44,30 +54,33 @@ struct gpu_brute_force_engine : public ann_engine<T, gpu_brute_force_engine<T>> 
 	explicit gpu_brute_force_engine(config c) : conf(c) {}
 	gpu_brute_force_engine(const gpu_brute_force_engine&) = delete;
 	gpu_brute_force_engine& operator=(const gpu_brute_force_engine&) = delete;
-	~gpu_brute_force_engine() { expann_destroy(handle); }
+	~gpu_brute_force_engine() {
+		expann_destroy(handle);
+		expann_sharded_destroy(sharded);
+	}
 
 	void _store_vector(const vec<T>& v) {
-		if (!handle)
+		if (!opened())
 			open(v.size());
 		if (v.size() != dimension)
 			throw std::runtime_error("gpu_brute_force_engine: row dimension changed");
 		std::vector<T> row(dimension);
 		for (size_t i = 0; i < dimension; ++i)
 			row[i] = v.at(i);
-		check(expann_add(handle, row.data(), 1));
+		check(sharded ? expann_sharded_add(sharded, row.data(), 1) : expann_add(handle, row.data(), 1));
 		++stored;
 	}
 	// batch form of store_vector (cf. store_many_vectors, src/pyrunner.cpp:60-82)
 	void store_rows(const T* rows, size_t n, size_t dim) {
-		if (!handle)
+		if (!opened())
 			open(dim);
-		check(expann_add(handle, rows, n));
+		check(sharded ? expann_sharded_add(sharded, rows, n) : expann_add(handle, rows, n));
 		stored += n;
 	}
 	void _build() {
-		if (!handle)
+		if (!opened())
 			throw std::runtime_error("gpu_brute_force_engine: build() on an empty index");
-		check(expann_build(handle));
+		check(sharded ? expann_sharded_build(sharded) : expann_build(handle));
 	}
 	std::vector<size_t> _query_k(const vec<T>& v, size_t k) {
 		std::vector<T> q(dimension);
@@ -83,26 +96,53 @@ struct gpu_brute_force_engine : public ann_engine<T, gpu_brute_force_engine<T>> 
 	// Extension (the reference has no batch API): ids[m][k] / dists[m][k], rows ascending,
 	// padded with UINT64_MAX / +inf when fewer than k rows exist.  dists may be nullptr.
 	void query_k_batch(const T* queries, size_t m, size_t k, uint64_t* ids, float* dists) {
-		if (!handle)
+		if (!opened())
 			throw std::runtime_error("gpu_brute_force_engine: query before build()");
-		check(expann_search(handle, queries, m, k, ids, dists));
+		check(sharded ? expann_sharded_search(sharded, queries, m, k, ids, dists)
+		              : expann_search(handle, queries, m, k, ids, dists));
 	}
 	const std::string _name() { return "GPU Brute-Force Engine (MI355X)"; }
 	const param_list_t _param_list() {
 		param_list_t pl;
 		pl["device"] = std::to_string(conf.device);
+		if (sharded) {
+			std::string d;
+			for (int x : conf.devices)
+				d += (d.empty() ? "" : ",") + std::to_string(x);
+			pl["devices"] = d;
+			pl["shards"] = std::to_string(expann_sharded_shards(sharded));
+		}
 		pl["metric"] = conf.metric == EXPANN_METRIC_IP ? "ip" : "l2";
 		pl["query_tile"] = std::to_string(conf.query_tile);
 		return pl;
 	}
 
 private:
+	// the row types the library stores (include/expann_hip.h, expann_dtype); anything else is a
+	// compile-time error rather than a silently wrong row type
 	static constexpr int dtype_of() {
-		return sizeof(T) == 4 ? EXPANN_DTYPE_F32 : EXPANN_DTYPE_I8;
+		static_assert(std::is_same<T, float>::value || std::is_same<T, uint8_t>::value ||
+		                  std::is_same<T, int8_t>::value || std::is_same<T, int16_t>::value,
+		              "gpu_brute_force_engine<T>: T must be float, uint8_t, int8_t or int16_t");
+		return std::is_same<T, float>::value     ? EXPANN_DTYPE_F32
+		       : std::is_same<T, uint8_t>::value ? EXPANN_DTYPE_U8
+		       : std::is_same<T, int8_t>::value  ? EXPANN_DTYPE_I8
+		                                         : EXPANN_DTYPE_I16;
 	}
+	bool opened() const { return handle || sharded; }
 	void open(size_t dim) {
 		dimension = dim;
-		int rc = expann_create(int(dim), dtype_of(), conf.metric, conf.device, &handle);
+		if (conf.devices.size() > 1) {
+			int rc = expann_sharded_create(int(dim), dtype_of(), conf.metric, conf.devices.data(),
+			                               int(conf.devices.size()), &sharded);
+			if (rc != EXPANN_OK)
+				throw std::runtime_error(std::string("expann_sharded_create: ") + expann_sharded_last_error(nullptr));
+			if (conf.query_tile)
+				check(expann_sharded_set_option(sharded, "query_tile", conf.query_tile));
+			return;
+		}
+		int rc = expann_create(int(dim), dtype_of(), conf.metric, conf.devices.empty() ? conf.device : conf.devices[0],
+		                       &handle);
 		if (rc != EXPANN_OK)
 			throw std::runtime_error(std::string("expann_create: ") + expann_last_error(nullptr));
 		if (conf.query_tile)
@@ -110,6 +150,7 @@ private:
 	}
 	void check(int rc) {
 		if (rc != EXPANN_OK)
-			throw std::runtime_error(std::string("expann_hip: ") + expann_last_error(handle));
+			throw std::runtime_error(std::string("expann_hip: ") +
+			                         (sharded ? expann_sharded_last_error(sharded) : expann_last_error(handle)));
 	}
 };

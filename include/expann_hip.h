@@ -126,6 +126,55 @@ int expann_merge_topk_strided_device(int device, const uint64_t* d_in_ids, const
                                      size_t ids_stride, size_t dists_stride, size_t n_lists, size_t m,
                                      size_t k, uint64_t* d_out_ids, float* d_out_dists, void* stream);
 
+/* row-sharded brute force over the GPUs of one node (SURVEY 8b "create(..., devices, n_dev, ...)",
+ * 8e; csrc/expann_sharded.hip) -------------------------------------------------------------------
+ * Shard r holds the contiguous rows [r * ceil(N/G), min(N, (r+1) * ceil(N/G))) and searches ALL
+ * queries on its own device; the fixed-size per-shard results [m][k] of (score, global id) are
+ * exchanged with ONE ncclAllGather (RCCL over xGMI) and merged in the reference's (score, id) order,
+ * so ids and distances are bit-identical to the single-device index (contiguous ranges + global
+ * ids).  The reference has no counterpart (one engine, one thread: src/basic_bench.h:83-84); the
+ * calls mirror the single-device ones above (engine construction src/bench_runner.h:33,
+ * store_vector / build / query_k src/ann_engine.h:23-29). */
+typedef struct expann_sharded expann_sharded;
+/* In-process form: ONE handle drives n_dev devices of this node (one stream per device,
+ * ncclCommInitAll at build).  devices[] may name a device more than once (several shards on one
+ * GPU; the exchange then runs as device copies, RCCL refuses duplicate devices). */
+int expann_sharded_create(int dim, int dtype, int metric, const int* devices, int n_dev,
+                          expann_sharded** out);
+/* One-process-per-GPU form: rank `rank` of `world` ranks on `device`; id128 = the 128 bytes rank 0
+ * got from expann_sharded_unique_id (ncclGetUniqueId), distributed by the launcher.  Collective:
+ * every rank calls it (ncclCommInitRank). */
+int expann_sharded_unique_id(void* id128);
+int expann_sharded_create_rank(int dim, int dtype, int metric, int device, int rank, int world,
+                               const void* id128, expann_sharded** out);
+void expann_sharded_destroy(expann_sharded* h);
+const char* expann_sharded_last_error(const expann_sharded* h);
+/* in-process form: store_vector x n into host staging, then build() cuts the rows into the ranges
+ * above and uploads each to its device (as expann_add / expann_build). */
+int expann_sharded_add(expann_sharded* h, const void* rows, size_t n);
+int expann_sharded_build(expann_sharded* h);
+/* Adopt rows already in the shard's device memory (as expann_set_base_device): the rank form's
+ * only way to receive rows (shard = 0, id_offset = global number of the rank's first row);
+ * in-process form: shards in order 0, 1, ... instead of add + build. */
+int expann_sharded_set_shard_device(expann_sharded* h, int shard, const void* d_rows, size_t n,
+                                    uint64_t id_offset);
+size_t expann_sharded_size(const expann_sharded* h);  /* rows over all local shards */
+int expann_sharded_shards(const expann_sharded* h);   /* shards in use (rank form: world) */
+int expann_sharded_exchange(const expann_sharded* h); /* 0 none (one shard), 1 RCCL, 2 device copies */
+/* in-process form, host buffers: as expann_search. */
+int expann_sharded_search(expann_sharded* h, const void* queries, size_t m, size_t k, uint64_t* ids,
+                          float* dists);
+/* rank form, device buffers on `stream` (NULL = the handle's own): local search, ncclAllGather,
+ * merge; every rank ends with the full ids[m][k] / dists[m][k].  Collective.  With the option
+ * "async_search" = 1 the call returns without a host wait (expann_sharded_sync, as expann_sync). */
+int expann_sharded_search_device(expann_sharded* h, const void* d_queries, size_t m, size_t k,
+                                 uint64_t* d_ids, float* d_dists, void* stream);
+int expann_sharded_sync(expann_sharded* h);
+/* "exchange" (in-process form: 0 auto, 1 RCCL, 2 device copies), "async_search" (in-process form:
+ * 1 (default) = the shards' searches are enqueued on all devices before the host waits for any);
+ * every other option goes to the shards' indexes (expann_set_option). */
+int expann_sharded_set_option(expann_sharded* h, const char* name, long value);
+
 /* batched candidate scoring (quantized_scorer::filter_by_score, src/quantizer.h:20-59):
  * for each of n_ids row ids (order kept) score against ONE query; keep (id, score) with
  * score < cutoff.  Host buffers; *n_kept receives the count. */
@@ -197,11 +246,16 @@ typedef struct expann_profile {
 	uint64_t candidates;      /* candidates kept by the last full scan (all queries)    */
 	uint64_t retries;         /* overflow retries since reset                           */
 	char scan_kernel[64];     /* name of the full-scan kernel last launched             */
+	uint64_t deferred_searches; /* searches since reset whose flag check was deferred to
+	                             * expann_sync ("async_search"); the others waited on the host */
 } expann_profile;
 /* enable != 0 brackets every full-scan launch with HIP events. */
 int expann_set_profiling(expann_index* h, int enable);
 /* synchronises the recorded events, fills *out and resets the accumulators. */
 int expann_get_profile(expann_index* h, expann_profile* out);
+/* the same for every shard / for one shard of a sharded handle */
+int expann_sharded_set_profiling(expann_sharded* h, int enable);
+int expann_sharded_get_profile(expann_sharded* h, int shard, expann_profile* out);
 
 /* integer options: "query_tile" (0 = auto), "cand_capacity" (0 = auto),
  * "scan_kernel" (0 = auto, 1 = direct VALU scan, 2 = GEMM form on the fp32 / int8 matrix

@@ -33,6 +33,22 @@ def test_driver_config_keys_and_result_fields(tmp_path):
     assert {bd["param_list"]["mode"] for bd in lines[1:]} == {"serial", "batched"}
 
 
+def test_driver_devices_flag_shards_the_engine(tmp_path):
+    """--devices a,b,c: gpu_brute_force_engine::config{devices} -> expann_sharded_* (here three shards
+    on the box's one GPU); the C++ job machinery sees the same engine interface, recall stays 1.0."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    out = subprocess.run([EXE, "--dataset", "Synthetic", "--n", "30000", "--m", "150", "--d", "128", "--k", "10",
+                          "--devices", "0,0,0", "--mode", "both"], capture_output=True, text=True,
+                         timeout=300, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(x) for x in out.stdout.strip().splitlines()]
+    assert len(lines) == 3
+    for bd in lines[1:]:
+        assert bd["recall"] == 1.0
+        assert bd["param_list"]["devices"] == "0,0,0" and bd["param_list"]["shards"] == "3"
+
+
 def test_driver_rejects_missing_parameters(tmp_path):
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])

@@ -125,10 +125,11 @@ def _grid_worker(rank, world, row_shards, port, n, d, m, k, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,row_shards,m", [(4, None, 10), (4, 4, 9), (2, None, 7), (6, 2, 10),
-                                                (3, None, 5), (2, 1, 7)])
+@pytest.mark.parametrize("world,row_shards,m", [(4, 2, 10), (4, None, 9), (2, None, 7), (6, 2, 10),
+                                                (3, None, 5), (2, 1, 7), (8, None, 12), (8, 2, 11)])
 def test_grid_sharded_search_matches_unsharded(world, row_shards, m):
-    """rows x queries grid (bench.py's default layout): every rank must end with the full,
+    """rows x queries grids (None = bench.py's default, pure row sharding; 8 ranks = the C3 node):
+    every rank must end with the full,
     unsharded answer, ragged query slices included."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -149,8 +150,9 @@ def test_shard_grid_defaults():
     from expann_amd.sharded import shard_grid
     assert shard_grid(1) == (1, 1)
     assert shard_grid(2) == (2, 1)
-    assert shard_grid(4) == (2, 2)
-    assert shard_grid(8) == (2, 4)
+    assert shard_grid(4) == (4, 1)      # default: pure row sharding
+    assert shard_grid(8) == (8, 1)
+    assert shard_grid(8, 2) == (2, 4)   # hybrid grid on request
     assert shard_grid(3) == (3, 1)
     assert shard_grid(8, 8) == (8, 1)
     with pytest.raises(ValueError):
