@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,6 +21,7 @@
 #include "scan_gemm_bf16.hpp"
 #include "scan_gemm_f16.hpp"
 #include "scan_gemm_f16k.hpp"
+#include "scan_gemm_f16x.hpp"
 #include "scan_direct_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
@@ -96,6 +98,12 @@ struct expann_index {
 	void* d_base_i8q = nullptr;      // padded int8 copy of an 8-bit index (uint8 rows ^ 0x80) or alias of d_base
 	bool base_i8q_owned = false;
 	int* d_bp_i8q = nullptr;         // [n padded] floor(bias/2), scan_gemm_i8q.hpp
+	void* d_log = nullptr;           // per-wave hit logs of scan_gemm_f16x ([n_logs][log_cap] x 16 B)
+	uint32_t* d_log_cnt = nullptr;   // [n_logs]
+	size_t log_bytes = 0, log_cnt_n = 0;
+	struct {                         // scatter_log_kernel of the scan just launched (run after its timing event)
+		uint32_t n_logs = 0, log_cap = 0, cap = 0, n_chunks = 0, n_qtiles = 0, xcd_map = 0, m = 0;
+	} pending_scatter;
 	float* d_sample = nullptr;       // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
 	size_t sample_bytes = 0;
 	void* d_q_split = nullptr;       // [m][2][dim] bf16 (or [m][dim] fp16)
@@ -132,6 +140,7 @@ struct expann_index {
 	                                 // full scan drowned in candidates (90 k instead of 2.8 M QPS on
 	                                 // 1000 contiguous clusters); on iid rows the two differ by < 1 %
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
+	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
@@ -403,6 +412,7 @@ struct GemmF16Variant {
 	F16PrepFn prep;
 	const char* name;
 	int tb, wgq, threads, wg_per_cu, lds;  // rows per tile, queries per workgroup, launch geometry
+	int hit_log;                           // scan writes per-wave hit logs (scan_gemm_f16x.hpp) + scatter_log_kernel
 };
 #define F16_V(D)                                                                                   \
 	{D, scan_gemm_f16_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,            \
@@ -415,8 +425,20 @@ struct GemmF16Variant {
 	 F16kGeom<D>::THREADS, 1, F16kGeom<D>::LDS_BYTES}
 const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(512),
                                    F16K_V(768), F16K_V(832), F16K_V(960)};
+// the 16x16x32 form of the full scan (scan_gemm_f16x.hpp); its sampled pass is the 32x32x16 kernel's
+#define F16X_V(D)                                                                                  \
+	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,           \
+	 f16_query_prep_kernel<D>, "scan_gemm_f16x<" #D ", false>", kF16TB, kF16TQ, kF16Threads, 2,      \
+	 gemm_f16_lds_bytes<128>(), 1}
+const GemmF16Variant kGemmF16X[] = {F16X_V(128)};
+#undef F16X_V
+// the same with the run-time ablation switches compiled in ("debug" option != 0)
+const GemmF16Variant kGemmF16XDbg[] = {{128, scan_gemm_f16x_kernel<128, false, 1>, scan_gemm_f16_kernel<128, true>,
+                                        sqnorm_kernel<128>, f16_query_prep_kernel<128>, "scan_gemm_f16x<128, false>",
+                                        kF16TB, kF16TQ, kF16Threads, 2, gemm_f16_lds_bytes<128>(), 1}};
 #undef F16_V
 #undef F16K_V
+inline bool f16_choice(long opt) { return opt == 0 || opt == 4 || opt == 6; }
 
 // a handful of queries: the same filter streamed from HBM without the matrix cores
 // (scan_direct_f16.hpp); tq = queries per pass
@@ -511,7 +533,7 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 		return nullptr;
 	if (h->metric == EXPANN_METRIC_IP) {
 		// inner product: only the fp16 form has it (a placeholder variant keeps the GEMM branch alive)
-		const bool ok = (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4) && h->f16_scale >= 0.0f &&
+		const bool ok = f16_choice(h->opt_scan_kernel) && h->f16_scale >= 0.0f &&
 		                !(h->opt_scan_kernel == 0 && ((m < 5 && !pick_direct_f16(h->dim, m)) || h->n < 4096));
 		if (ok)
 			for (const auto& v : kGemmF16Only)
@@ -532,7 +554,7 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 	for (const auto& v : kGemmF32)
 		if (v.d == h->dim)
 			return &v;
-	if (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4)
+	if (f16_choice(h->opt_scan_kernel))
 		for (const auto& v : kGemmF16Only)
 			if (v.d == h->dim)
 				return &v;
@@ -1203,8 +1225,38 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 		*kname = dv->name;
 		*query_tile = (uint32_t)dv->tq;
 	} else {
-		hipLaunchKernelGGL(gvf->scan, dim3(fchunks * fp.n_qtiles), dim3((uint32_t)gvf->threads), gvf->lds,
-		                   st, fp);
+		const uint32_t grid = fchunks * fp.n_qtiles;
+		if (gvf->hit_log) {
+			// one log per wave, together as large as the candidate lists they are filed into
+			const uint32_t n_logs = grid * (uint32_t)(gvf->threads / 64);
+			const uint32_t log_cap = std::max<uint32_t>(1024, pow2ceil((uint32_t)std::min<size_t>(
+			                                                      (m * (size_t)cap + n_logs - 1) / n_logs, 1u << 20)));
+			const size_t need = (size_t)n_logs * log_cap * 16;
+			if (need > h->log_bytes || n_logs > h->log_cnt_n) {
+				HIP_TRY(h, hipStreamSynchronize(st));
+				if (h->d_log) hipFree(h->d_log);
+				if (h->d_log_cnt) hipFree(h->d_log_cnt);
+				h->d_log = nullptr;
+				h->d_log_cnt = nullptr;
+				h->log_bytes = h->log_cnt_n = 0;
+				HIP_TRY(h, hipMalloc(&h->d_log, need));
+				HIP_TRY(h, hipMalloc(&h->d_log_cnt, sizeof(uint32_t) * n_logs));
+				h->log_bytes = need;
+				h->log_cnt_n = n_logs;
+			}
+			fp.log = (uint4*)h->d_log;
+			fp.log_cnt = h->d_log_cnt;
+			fp.log_cap = log_cap;
+			fp.lost = h->d_overflow;
+			h->pending_scatter.n_logs = n_logs;
+			h->pending_scatter.log_cap = log_cap;
+			h->pending_scatter.cap = cap;
+			h->pending_scatter.n_chunks = fchunks;
+			h->pending_scatter.n_qtiles = fp.n_qtiles;
+			h->pending_scatter.xcd_map = fp.xcd_map;
+			h->pending_scatter.m = (uint32_t)m;
+		}
+		hipLaunchKernelGGL(gvf->scan, dim3(grid), dim3((uint32_t)gvf->threads), gvf->lds, st, fp);
 		*kname = gvf->name;
 	}
 	*n_qtiles = fp.n_qtiles;
@@ -1217,6 +1269,9 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 		HIP_TRY(h, hipMemcpy(c, fp.clk, sizeof(c), hipMemcpyDeviceToHost));
 		std::fprintf(stderr, "scan_gemm_f16 wg0: %llu shader clocks in %.1f us = %.0f MHz\n", c[0],
 		             c[1] / 100.0, c[1] ? c[0] * 100.0 / c[1] : 0.0);
+		if (c[6])
+			std::fprintf(stderr, "  per step (%llu steps): columns 0-1 %.0f, stage wait + barrier %.0f, columns 2-3 %.0f, tail + queue work %.0f cycles\n",
+			             c[6], (double)c[2] / c[6], (double)c[3] / c[6], (double)c[4] / c[6], (double)c[5] / c[6]);
 	}
 	return EXPANN_OK;
 }
@@ -1323,11 +1378,16 @@ restart_direct:
 	// fp16 single-product form: default when available; a search whose queries leave the fp16
 	// range after scaling is redone with the bf16x3 form (no_f16)
 	const GemmF16Variant* gvf = nullptr;
-	if (gv && !no_f16 && (h->opt_scan_kernel == 0 || h->opt_scan_kernel == 4))
+	if (gv && !no_f16 && f16_choice(h->opt_scan_kernel)) {
 		for (const auto& v : kGemmF16)
 			if (v.d == h->dim)
 				gvf = &v;
-	if (h->opt_scan_kernel == 4 && !gvf && !no_f16)
+		if (h->opt_scan_kernel == 6 || (h->opt_scan_kernel == 0 && h->opt_f16x))
+			for (const auto& v : ((h->opt_debug & ~16L) ? kGemmF16XDbg : kGemmF16X))
+				if (v.d == h->dim)
+					gvf = &v;
+	}
+	if ((h->opt_scan_kernel == 4 || h->opt_scan_kernel == 6) && !gvf && !no_f16)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
 	if (gvf)
 		gvb = nullptr;
@@ -1589,6 +1649,17 @@ restart_direct:
 				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 				h->ev_used++;
 			}
+			if (h->pending_scatter.n_logs) {  // scan_gemm_f16x: file the per-wave hit logs into the lists
+				const auto ps = h->pending_scatter;
+				h->pending_scatter.n_logs = 0;
+				// ~1024 workgroups: the logs of a (query tile, wave) pair are split over n_groups of them
+				const uint32_t want = std::max<uint32_t>(1, (1024 + ps.n_qtiles * 4 - 1) / (ps.n_qtiles * 4));
+				const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
+				const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
+				GatherLogParams gp{(const uint4*)h->d_log, (const uint32_t*)h->d_log_cnt, ps.log_cap, ps.n_chunks,
+				                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
+				hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
+			}
 			if (last && (timed || !h->profiling)) {
 				h->prof.scan_launches++;
 				h->prof.scan_rows += h->n;
@@ -1673,6 +1744,10 @@ restart_direct:
 			return EXPANN_OK;
 		// some candidate list overflowed: retry with 4x the capacity
 		h->prof.retries++;
+		if (gvf && gvf->hit_log)  // (or a hit log / queue of the 16x16x32 form: the direct appends have no such limit)
+			for (const auto& v : kGemmF16)
+				if (v.d == h->dim)
+					gvf = &v;
 		if ((cap >= kMaxCap || attempt >= 3) && (gv || gvi) && h->opt_scan_kernel == 0) {
 			// the GEMM forms cannot break exact ties by row number; the direct scan can
 			force_direct = true;
@@ -1771,6 +1846,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : (dtype == EXPANN_DTYPE_I16 ? 2 : 1);
 	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : (dtype == EXPANN_DTYPE_I16 ? 2 : 4);
 	h->int_mode = int_mode;
+	if (const char* e = std::getenv("EXPANN_F16X"))  // A/B switch of the fp16 scan's MFMA shape (tests, bench)
+		h->opt_f16x = std::atol(e);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -1792,6 +1869,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) !=
 			        hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
+				hipStreamDestroy(h->stream);
+				delete h;
+				return EXPANN_ERR_HIP;
+			}
+	for (const auto* tab : {kGemmF16X, kGemmF16XDbg})
+		if (tab[0].d == dim)
+			if (hipFuncSetAttribute((const void*)tab[0].scan, hipFuncAttributeMaxDynamicSharedMemorySize, tab[0].lds) !=
+			    hipSuccess) {
+				g_create_error = "hipFuncSetAttribute(scan_gemm_f16x_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
 				return EXPANN_ERR_HIP;
@@ -1860,6 +1946,8 @@ void expann_destroy(expann_index* h) {
 	if (h->d_bns_f16) hipFree(h->d_bns_f16);
 	if (h->d_qnrm) hipFree(h->d_qnrm);
 	if (h->d_sample) hipFree(h->d_sample);
+	if (h->d_log) hipFree(h->d_log);
+	if (h->d_log_cnt) hipFree(h->d_log_cnt);
 	if (h->d_base_i8q && h->base_i8q_owned) hipFree(h->d_base_i8q);
 	if (h->d_bp_i8q) hipFree(h->d_bp_i8q);
 	if (h->d_base_split) hipFree(h->d_base_split);
@@ -2299,6 +2387,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_debug = value;
 	else if (!std::strcmp(name, "scan_kernel"))
 		h->opt_scan_kernel = value;
+	else if (!std::strcmp(name, "f16x"))
+		h->opt_f16x = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

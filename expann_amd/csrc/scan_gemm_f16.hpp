@@ -215,7 +215,77 @@ struct GemmF16Params {
 	// {x, x+8, ...} and all their query tiles go to XCD x, so a tile is fetched into ONE L2
 	// instead of eight.  Needs the chunk count to be a multiple of 8.
 	uint32_t xcd_map;
+	// scan_gemm_f16x_kernel only: every wave appends its hits to a log of its own in global memory --
+	// log[(4 blockIdx.x + wave) * log_cap + i] = {key, query}, plain stores in the wave's own order, no
+	// atomic and no returned value to wait for inside the MFMA kernel -- and leaves the count in
+	// log_cnt; scatter_log_kernel then files the entries into the per-query lists (cand, cand_cnt).
+	// *lost is incremented by a wave whose log or LDS queue overflowed (the host repeats the search
+	// with scan_gemm_f16_kernel, whose direct appends have no such limit).
+	uint4* log;
+	uint32_t* log_cnt;
+	uint32_t log_cap;
+	uint32_t* lost;
 };
+
+// Per-wave hit logs -> per-query candidate lists.  The 64 queries of (query tile, wave w) receive
+// hits from exactly the n_chunks logs of wave w in the workgroups (chunk, query tile); a workgroup
+// here takes `chunks_per_block` of those logs: it counts its entries per query in LDS, reserves the
+// slots of each query with ONE global atomicAdd (64 per workgroup instead of one per hit), then
+// files the entries.  cand_cnt is zero when the kernel starts (sample_tau_kernel / the level's memset).
+// grid = n_qtiles * 4 * n_groups; block index = (qtile * 4 + w) * n_groups + group.
+struct GatherLogParams {
+	const uint4* log;
+	const uint32_t* log_cnt;
+	uint32_t log_cap, n_chunks, n_qtiles, xcd_map, m;
+	uint32_t n_groups, chunks_per_block;
+	uint32_t* cand_cnt;
+	uint64_t* cand;
+	uint32_t cap;
+};
+__global__ __launch_bounds__(kBlock) void gather_logs_kernel(GatherLogParams p) {
+	__shared__ uint32_t cnt[64], base[64];
+	const uint32_t grp = blockIdx.x % p.n_groups, qw = blockIdx.x / p.n_groups;
+	const uint32_t qtile = qw >> 2, w = qw & 3;
+	const uint32_t q0 = qtile * 256 + w * 64;
+	if (threadIdx.x < 64)
+		cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t c0 = grp * p.chunks_per_block;
+	const uint32_t c1 = c0 + p.chunks_per_block < p.n_chunks ? c0 + p.chunks_per_block : p.n_chunks;
+	auto log_of = [&](uint32_t c, uint32_t& n) -> const uint4* {
+		const uint32_t bid = p.xcd_map ? ((c >> 3) * p.n_qtiles + qtile) * 8 + (c & 7) : c * p.n_qtiles + qtile;
+		const uint32_t li = bid * 4 + w;
+		n = p.log_cnt[li];
+		if (n > p.log_cap)
+			n = p.log_cap;
+		return p.log + (size_t)li * p.log_cap;
+	};
+	for (uint32_t c = c0 + wv; c < c1; c += kBlock / 64) {  // one wave per log
+		uint32_t n;
+		const uint4* src = log_of(c, n);
+		for (uint32_t i = lane; i < n; i += 64)
+			atomicAdd(&cnt[(src[i].z - q0) & 63], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 64) {
+		const uint32_t n = cnt[threadIdx.x];
+		base[threadIdx.x] = n ? atomicAdd(&p.cand_cnt[q0 + threadIdx.x], n) : 0u;
+		cnt[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	for (uint32_t c = c0 + wv; c < c1; c += kBlock / 64) {
+		uint32_t n;
+		const uint4* src = log_of(c, n);
+		for (uint32_t i = lane; i < n; i += 64) {
+			const uint4 e = src[i];
+			const uint32_t ql = (e.z - q0) & 63;
+			const uint32_t slot = base[ql] + atomicAdd(&cnt[ql], 1u);
+			if (slot < p.cap)
+				p.cand[(size_t)e.z * p.cap + slot] = ((uint64_t)e.y << 32) | e.x;
+		}
+	}
+}
 
 __device__ inline float max3f(float a, float b, float c) {
 	return __builtin_fmaxf(__builtin_fmaxf(a, b), c);  // folds to v_max3_f32
@@ -462,6 +532,8 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
 				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (WGQ - 1)]) * p.two_inv_s2, e.row);
 			}
+			if (p.debug & 64)
+				continue;  // (ablation: the queue is emptied, nothing reaches the lists)
 #pragma unroll
 			for (int j = 0; j < R; ++j)
 				slot[j] = hit[j] ? atomicAdd(&p.cand_cnt[qi[j]], 1u) : 0xFFFFFFFFu;
