@@ -183,7 +183,7 @@ def profiled_traffic(kernel_name):
         for x in mm.group(2).split(","):
             x = x.strip()
             args.append({"L2": 0, "false": 0, "IP": 1, "true": 1}.get(x, x))
-        return (mm.group(1), tuple(str(x) for x in args))
+        return (mm.group(1), tuple(str(x) for x in args[:2]))   # (dimension, variant); further template arguments are build switches
 
     want = norm(kernel_name)
     if not want:

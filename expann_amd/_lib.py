@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "expann_antitopo_store", "expann_antitopo_build", "expann_antitopo_set_ef_search",
     "expann_antitopo_query", "expann_antitopo_save", "expann_antitopo_load",
     "expann_antitopo_size", "expann_antitopo_num_distcomps",
+    "expann_graph_build_batched", "expann_antitopo_store_batched",
     "expann_sharded_create", "expann_sharded_unique_id", "expann_sharded_create_rank",
     "expann_sharded_destroy", "expann_sharded_last_error", "expann_sharded_add", "expann_sharded_build",
     "expann_sharded_set_shard_device", "expann_sharded_size", "expann_sharded_shards",
@@ -148,6 +149,8 @@ def load():
     L.expann_antitopo_last_error.argtypes = [vp]
     L.expann_antitopo_store.restype = C.c_int
     L.expann_antitopo_store.argtypes = [vp, vp, sz]
+    L.expann_antitopo_store_batched.restype = C.c_int
+    L.expann_antitopo_store_batched.argtypes = [vp, vp, sz, sz]
     L.expann_antitopo_build.restype = C.c_int
     L.expann_antitopo_build.argtypes = [vp]
     L.expann_antitopo_set_ef_search.restype = C.c_int

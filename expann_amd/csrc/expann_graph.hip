@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "graph_build.hpp"
 #include "graph_search.hpp"
 #include "host_common.hpp"
 #include "quantize.hpp"
@@ -278,6 +279,243 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	return EXPANN_OK;
 }
 
+// ---- GPU-assisted batched construction (graph_build.hpp) -------------------------------------
+namespace {
+using BuildSearchFn = void (*)(BuildSearchParams);
+using BuildPruneFn = void (*)(BuildPruneParams);
+struct BuildVariant {
+	int d;
+	BuildSearchFn search;
+	BuildPruneFn prune;
+};
+#define BUILD_V(D) {D, build_search_kernel<D>, build_prune_kernel<D>}
+const BuildVariant kBuild[] = {BUILD_V(64), BUILD_V(128), BUILD_V(256), BUILD_V(832), BUILD_V(960)};
+#undef BUILD_V
+struct BuildFail {
+	std::string msg;
+};
+}  // namespace
+
+int expann_graph_build_batched(int dim, int device, const float* vectors, size_t n, const uint8_t* levels,
+                               size_t n_built, uint32_t* max_layer_io, uint32_t* starting_vertex_io, size_t M,
+                               size_t M0, size_t ef_construction, size_t prune_overflow, float ortho_factor,
+                               float ortho_bias, size_t max_batch, uint32_t* ids0, float* d0, uint32_t* deg0,
+                               size_t stride0, const int32_t* upper_idx, size_t U, size_t n_upper_layers,
+                               uint32_t* idsu, float* du, uint32_t* degu, size_t strideu, uint64_t* stats) {
+	const BuildVariant* bv = nullptr;
+	for (const auto& v : kBuild)
+		if (v.d == dim)
+			bv = &v;
+	if (!bv) {
+		g_create_error = "graph build is compiled for dim 64, 128, 256, 832, 960";
+		return EXPANN_ERR_UNSUPPORTED;
+	}
+	if (!vectors || !levels || !max_layer_io || !starting_vertex_io || !ids0 || !d0 || !deg0 || !upper_idx ||
+	    n == 0 || n_built == 0 || n_built > n || n >= (1ull << 32) - 64 || M < 2 || M0 < M || stride0 < M0 ||
+	    (n_upper_layers && (!idsu || !du || !degu || strideu < M)) || ef_construction == 0 ||
+	    ef_construction > (size_t)kPruneMaxCand || stride0 > (size_t)kPruneMaxCand ||
+	    strideu > (size_t)kPruneMaxCand || *max_layer_io == 0 || *max_layer_io > n_upper_layers + 1 ||
+	    *starting_vertex_io >= n_built) {
+		g_create_error = "expann_graph_build_batched: bad arguments (ef_construction and row strides <= 1024)";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	if (expann_device_count() <= device || device < 0) {
+		g_create_error = "no such HIP device: libexpann_hip has no CPU fallback";
+		return EXPANN_ERR_NO_DEVICE;
+	}
+	struct Fail {
+		int fail(int code, const std::string& m) const {
+			g_create_error = "expann_graph_build_batched: " + m;
+			return code;
+		}
+	} F;
+	Fail* fh = &F;
+	HIP_TRY(fh, hipSetDevice(device));
+	hipStream_t st = nullptr;
+	HIP_TRY(fh, hipStreamCreate(&st));
+	DevBuf b_vec, b_lvl, b_up, b_id0, b_d0, b_deg0, b_idu, b_du, b_degu, b_vis, b_ep, b_out, b_outc, b_tasks, b_upslot,
+	    b_dirty, b_ctr;
+	const size_t n_up_rows = U * n_upper_layers;
+	HIP_TRY(fh, b_vec.alloc(n * (size_t)dim * 4));
+	HIP_TRY(fh, b_lvl.alloc(n));
+	HIP_TRY(fh, b_up.alloc(n * 4));
+	HIP_TRY(fh, b_id0.alloc(n * stride0 * 4));
+	HIP_TRY(fh, b_d0.alloc(n * stride0 * 4));
+	HIP_TRY(fh, b_deg0.alloc(n * 4));
+	HIP_TRY(fh, b_idu.alloc(std::max<size_t>(1, n_up_rows * strideu) * 4));
+	HIP_TRY(fh, b_du.alloc(std::max<size_t>(1, n_up_rows * strideu) * 4));
+	HIP_TRY(fh, b_degu.alloc(std::max<size_t>(1, n_up_rows) * 4));
+	HIP_TRY(fh, hipMemcpy(b_vec.p, vectors, n * (size_t)dim * 4, hipMemcpyHostToDevice));
+	HIP_TRY(fh, hipMemcpy(b_lvl.p, levels, n, hipMemcpyHostToDevice));
+	HIP_TRY(fh, hipMemcpy(b_up.p, upper_idx, n * 4, hipMemcpyHostToDevice));
+	HIP_TRY(fh, hipMemcpy(b_id0.p, ids0, n * stride0 * 4, hipMemcpyHostToDevice));
+	HIP_TRY(fh, hipMemcpy(b_d0.p, d0, n * stride0 * 4, hipMemcpyHostToDevice));
+	HIP_TRY(fh, hipMemcpy(b_deg0.p, deg0, n * 4, hipMemcpyHostToDevice));
+	if (n_up_rows) {
+		HIP_TRY(fh, hipMemcpy(b_idu.p, idsu, n_up_rows * strideu * 4, hipMemcpyHostToDevice));
+		HIP_TRY(fh, hipMemcpy(b_du.p, du, n_up_rows * strideu * 4, hipMemcpyHostToDevice));
+		HIP_TRY(fh, hipMemcpy(b_degu.p, degu, n_up_rows * 4, hipMemcpyHostToDevice));
+	}
+	BuildGraph g{};
+	g.vec = b_vec.as<float>();
+	g.n = (uint32_t)n;
+	g.level = b_lvl.as<uint8_t>();
+	g.upper_idx = b_up.as<int32_t>();
+	g.id0 = b_id0.as<uint32_t>();
+	g.d0 = b_d0.as<float>();
+	g.deg0 = b_deg0.as<uint32_t>();
+	g.cap0 = (uint32_t)M0;
+	g.stride0 = (uint32_t)stride0;
+	g.idu = b_idu.as<uint32_t>();
+	g.du = b_du.as<float>();
+	g.degu = b_degu.as<uint32_t>();
+	g.capu = (uint32_t)M;
+	g.strideu = (uint32_t)strideu;
+	g.U = (uint32_t)U;
+
+	const int cus = num_cus(device);
+	if (max_batch == 0)
+		max_batch = 32768;
+	// search: one wave per new vertex; LDS = nearest heap + candidates heap + a hop's neighbour list
+	const uint32_t list_cap = (uint32_t)std::max(stride0, std::max(strideu, ef_construction));
+	uint32_t cand_cap = 8192;
+	const size_t search_lds = sizeof(md_pair) * (ef_construction + 1 + cand_cap + 1) +
+	                          (sizeof(uint32_t) + sizeof(float)) * list_cap + 8 * sizeof(uint32_t);
+	HIP_TRY(fh, hipFuncSetAttribute((const void*)bv->search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)search_lds));
+	uint64_t slots = (uint64_t)cus * 2;  // resident search workgroups (two 72 KB workgroups per CU)
+	while (slots > 64 && slots * n > (32ull << 30))
+		slots /= 2;
+	HIP_TRY(fh, b_vis.alloc(slots * n));
+	HIP_TRY(fh, b_ep.alloc(slots * 4));
+	HIP_TRY(fh, hipMemset(b_vis.p, 0, slots * n));
+	HIP_TRY(fh, hipMemset(b_ep.p, 0, slots * 4));
+	const size_t max_up_in_batch = max_batch * (n_upper_layers ? 1 : 0) + 64;  // (bounded below per batch)
+	HIP_TRY(fh, b_out.alloc((max_batch + max_up_in_batch) * ef_construction * sizeof(md_pair)));
+	HIP_TRY(fh, b_outc.alloc((max_batch + max_up_in_batch) * 4));
+	HIP_TRY(fh, b_tasks.alloc((max_batch + max_up_in_batch) * sizeof(PruneTask)));
+	HIP_TRY(fh, b_upslot.alloc(max_batch * 4));
+	const size_t dirty_cap = n + n_up_rows + 1;
+	HIP_TRY(fh, b_dirty.alloc(dirty_cap * sizeof(uint2)));
+	HIP_TRY(fh, b_ctr.alloc(8 * 4));  // [0] n_dirty, [1] dropped, [2] search overflow, [3] n_tasks
+	HIP_TRY(fh, hipMemset(b_ctr.p, 0, 8 * 4));
+	uint32_t* ctr = b_ctr.as<uint32_t>();
+
+	uint32_t max_layer = *max_layer_io, starting_vertex = *starting_vertex_io;
+	uint64_t n_batches = 0, n_dirty_total = 0;
+	std::vector<PruneTask> tasks;
+	std::vector<int32_t> up_slot;
+	size_t b0 = n_built;
+	while (b0 < n) {
+		// a batch: at most 1/8 of the graph so far; a vertex that opens a new layer goes alone
+		size_t b1 = std::min(n, b0 + std::min(max_batch, std::max<size_t>(1, b0 / 8)));
+		for (size_t v = b0; v < b1; ++v)
+			if (levels[v] >= max_layer) {
+				b1 = v == b0 ? v + 1 : v;
+				break;
+			}
+		const uint32_t B = (uint32_t)(b1 - b0);
+		tasks.clear();
+		up_slot.assign(B, -1);
+		uint32_t n_up = 0;
+		for (uint32_t i = 0; i < B; ++i)
+			tasks.push_back(PruneTask{(uint32_t)(b0 + i), 0u, (int32_t)i});
+		for (uint32_t i = 0; i < B; ++i) {
+			const uint32_t lv = std::min<uint32_t>(levels[b0 + i], max_layer - 1);
+			if (lv >= 1) {
+				up_slot[i] = (int32_t)n_up;
+				for (uint32_t l = 1; l <= lv; ++l)
+					tasks.push_back(PruneTask{(uint32_t)(b0 + i), l, (int32_t)(B + n_up + l - 1)});
+				n_up += lv;
+			}
+		}
+		if (n_up > max_up_in_batch)
+			return F.fail(EXPANN_ERR_UNSUPPORTED, "more upper-layer vertices in a batch than provisioned");
+		const uint32_t n_tasks = (uint32_t)tasks.size();
+		HIP_TRY(fh, hipMemcpyAsync(b_tasks.p, tasks.data(), sizeof(PruneTask) * n_tasks, hipMemcpyHostToDevice, st));
+		HIP_TRY(fh, hipMemcpyAsync(b_upslot.p, up_slot.data(), 4 * B, hipMemcpyHostToDevice, st));
+		HIP_TRY(fh, hipMemcpyAsync(ctr + 3, &n_tasks, 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(fh, hipMemsetAsync(ctr, 0, 4, st));
+		BuildSearchParams sp{};
+		sp.g = g;
+		sp.b0 = (uint32_t)b0;
+		sp.b1 = (uint32_t)b1;
+		sp.max_layer = max_layer;
+		sp.starting_vertex = starting_vertex;
+		sp.ef = (uint32_t)ef_construction;
+		sp.cand_cap = cand_cap;
+		sp.list_cap = list_cap;
+		sp.visited = b_vis.as<uint8_t>();
+		sp.epochs = b_ep.as<uint32_t>();
+		sp.up_slot = b_upslot.as<int32_t>();
+		sp.out = b_out.as<md_pair>();
+		sp.out_cnt = b_outc.as<uint32_t>();
+		sp.error = ctr + 2;
+		hipLaunchKernelGGL(bv->search, dim3((uint32_t)std::min<uint64_t>(B, slots)), dim3(64), search_lds, st, sp);
+		BuildPruneParams pp{};
+		pp.g = g;
+		pp.tasks = b_tasks.as<PruneTask>();
+		pp.n_tasks = ctr + 3;
+		pp.lists = b_out.as<md_pair>();
+		pp.list_cnt = b_outc.as<uint32_t>();
+		pp.ef = (uint32_t)ef_construction;
+		pp.ortho_factor = ortho_factor;
+		pp.ortho_bias = ortho_bias;
+		pp.prune_overflow = (uint32_t)prune_overflow;
+		hipLaunchKernelGGL(bv->prune, dim3(std::min<uint32_t>(n_tasks, (uint32_t)cus * 16)), dim3(kPruneThreads), 0, st, pp);
+		BuildReverseParams rp{};
+		rp.g = g;
+		rp.tasks = b_tasks.as<PruneTask>();
+		rp.n_tasks = n_tasks;
+		rp.dirty = b_dirty.as<uint2>();
+		rp.n_dirty = ctr;
+		rp.dirty_cap = (uint32_t)dirty_cap;
+		rp.dropped = ctr + 1;
+		hipLaunchKernelGGL(build_reverse_kernel, dim3((n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, rp);
+		// the rows that outgrew their cap: clamp to the slack, prune (grid-stride over the dirty list)
+		hipLaunchKernelGGL(build_clamp_kernel, dim3((uint32_t)((dirty_cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g,
+		                   (const uint2*)b_dirty.p, (const uint32_t*)ctr);
+		BuildPruneParams dp = pp;
+		dp.tasks = nullptr;
+		dp.n_tasks = ctr;
+		dp.dirty = b_dirty.as<uint2>();
+		hipLaunchKernelGGL(bv->prune, dim3((uint32_t)cus * 16), dim3(kPruneThreads), 0, st, dp);
+		HIP_TRY(fh, hipGetLastError());
+		uint32_t h_ctr[4];
+		HIP_TRY(fh, hipMemcpyAsync(h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
+		HIP_TRY(fh, hipStreamSynchronize(st));
+		if (h_ctr[2])
+			return F.fail(EXPANN_ERR_OVERFLOW, "construction search: candidates queue overflowed its LDS capacity");
+		n_dirty_total += h_ctr[0];
+		++n_batches;
+		for (size_t v = b0; v < b1; ++v)  // :461-464
+			while (levels[v] >= max_layer) {
+				++max_layer;
+				starting_vertex = (uint32_t)v;
+			}
+		b0 = b1;
+	}
+	HIP_TRY(fh, hipMemcpy(ids0, b_id0.p, n * stride0 * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(fh, hipMemcpy(d0, b_d0.p, n * stride0 * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(fh, hipMemcpy(deg0, b_deg0.p, n * 4, hipMemcpyDeviceToHost));
+	if (n_up_rows) {
+		HIP_TRY(fh, hipMemcpy(idsu, b_idu.p, n_up_rows * strideu * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(fh, hipMemcpy(du, b_du.p, n_up_rows * strideu * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(fh, hipMemcpy(degu, b_degu.p, n_up_rows * 4, hipMemcpyDeviceToHost));
+	}
+	uint32_t h_ctr[4];
+	HIP_TRY(fh, hipMemcpy(h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost));
+	(void)hipStreamDestroy(st);
+	*max_layer_io = max_layer;
+	*starting_vertex_io = starting_vertex;
+	if (stats) {
+		stats[0] = n_batches;
+		stats[1] = h_ctr[1];
+		stats[2] = n_dirty_total;
+		stats[3] = h_ctr[2];
+	}
+	return EXPANN_OK;
+}
+
 // ---- the graph engine behind one handle (host build + device queries) --------------------
 }  // extern "C"
 
@@ -339,6 +577,13 @@ int expann_antitopo_store(expann_antitopo* e, const float* rows, size_t n) {
 	if (!e || (!rows && n))
 		return EXPANN_ERR_INVALID_ARG;
 	ANTITOPO_TRY(e, for (size_t i = 0; i < n; ++i) e->eng->index.insert(rows + i * (size_t)e->dim));
+	return EXPANN_OK;
+}
+
+int expann_antitopo_store_batched(expann_antitopo* e, const float* rows, size_t n, size_t n_serial) {
+	if (!e || (!rows && n))
+		return EXPANN_ERR_INVALID_ARG;
+	ANTITOPO_TRY(e, e->eng->store_rows_batched(rows, n, n_serial ? n_serial : 2048));
 	return EXPANN_OK;
 }
 

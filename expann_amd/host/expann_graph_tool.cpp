@@ -5,7 +5,7 @@
 //
 //   expann_graph_tool --n 5000 --m 200 --d 128 --k 10 --M 16 --ef_construction 100 \
 //       --data sift|gauss --index out.index --queries out.queries --results out.results \
-//       [--ef 10,20,40] [--build-only 1] [--read-index 1] [--prune_overflow 0|1]
+//       [--ef 10,20,40] [--build-only 1] [--read-index 1] [--prune_overflow 0|1] [--batched 2048]
 //
 // Files: <queries> raw m*d float32; <results> for each (compression in {0,1}) x (ef in list):
 // m*k uint64 ids, m*k float32 dists, m uint32 distcomps, in that order.  One JSON line per
@@ -34,6 +34,8 @@ int main(int argc, char** argv) {
 	             d = std::stoul(get("d", "128")), k = std::stoul(get("k", "10"));
 	const size_t M = std::stoul(get("M", "16")), efc = std::stoul(get("ef_construction", "100"));
 	const size_t prune_overflow = std::stoul(get("prune_overflow", "0"));
+	// --batched S: rows beyond the first S go through the batched GPU builder (0 = serial host build)
+	const size_t batched = std::stoul(get("batched", "0"));
 	const bool sift = get("data", "sift") == "sift";
 	const bool build_only = get("build-only", "0") == "1", read_index = get("read-index", "0") == "1";
 	const std::string index_path = get("index", "graph.index");
@@ -63,8 +65,14 @@ int main(int argc, char** argv) {
 		cfg.write_index = !read_index;
 		gpu_antitopo_engine<float> eng(cfg);
 		auto t0 = std::chrono::high_resolution_clock::now();
-		for (size_t i = 0; i < n; ++i)
-			eng.store_vector(vec<float>(base.data() + i * d, d));
+		std::vector<uint64_t> bstats;
+		if (batched && !read_index) {
+			eng.index.dim = d;
+			bstats = eng.store_rows_batched(base.data(), n, batched);
+		} else {
+			for (size_t i = 0; i < n; ++i)
+				eng.store_vector(vec<float>(base.data() + i * d, d));
+		}
 		if (build_only) {
 			if (!read_index)
 				eng.index.write_index(index_path);
@@ -75,9 +83,12 @@ int main(int argc, char** argv) {
 		}
 		auto t1 = std::chrono::high_resolution_clock::now();
 		std::printf("{\"phase\":\"build\",\"n\":%zu,\"d\":%zu,\"M\":%zu,\"ef_construction\":%zu,"
-		            "\"max_layer\":%zu,\"time_to_build_ns\":%.0f}\n",
+		            "\"max_layer\":%zu,\"time_to_build_ns\":%.0f,\"builder\":\"%s\",\"batches\":%llu,"
+		            "\"dropped_reverse_edges\":%llu,\"rows_repruned\":%llu}\n",
 		            eng.index.size(), d, M, efc, eng.index.max_layer,
-		            double(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count()));
+		            double(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count()),
+		            bstats.empty() ? "serial host" : "batched gpu", bstats.empty() ? 0ull : (unsigned long long)bstats[0],
+		            bstats.empty() ? 0ull : (unsigned long long)bstats[1], bstats.empty() ? 0ull : (unsigned long long)bstats[2]);
 		if (a.count("queries")) {
 			std::ofstream qf(a["queries"], std::ios::binary);
 			qf.write(reinterpret_cast<const char*>(queries.data()), (std::streamsize)(queries.size() * 4));

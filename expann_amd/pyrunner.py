@@ -82,6 +82,15 @@ class AntitopoEngine:
             a = np.ascontiguousarray(a, dtype=np.float32)
         self._check(self._L.expann_antitopo_store(self._h, a.ctypes.data, a.shape[0]))
 
+    def store_many_vectors_batched(self, array2d, take_norms=False, n_serial=2048):
+        """store_many_vectors through the batched GPU builder (csrc/graph_build.hpp): the first
+        n_serial rows of an empty engine are inserted serially, the rest in batches on the GPU."""
+        a = self._pad(array2d)
+        if take_norms:
+            a = a / np.sqrt(np.einsum("ij,ij->i", a, a, dtype=np.float32))[:, None]
+            a = np.ascontiguousarray(a, dtype=np.float32)
+        self._check(self._L.expann_antitopo_store_batched(self._h, a.ctypes.data, a.shape[0], int(n_serial)))
+
     def build(self):
         if self._h is None:
             raise _lib.ExpannError(_lib.ERR_INVALID_ARG, "build() on an empty index")

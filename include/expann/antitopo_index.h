@@ -314,15 +314,16 @@ struct antitopo_index {
 	}
 
 	// ---- src/antitopo_engine.h:310-465 ------------------------------------------------
-	void insert(const float* v) {
+	// the level draw of _store_vector (:323), one per vertex in insertion order
+	size_t draw_level() { return (size_t)std::floor(-std::log(gen.uniform01()) * 1 / std::log(double(conf.M))); }
+	void insert(const float* v) { insert_with_level(v, draw_level()); }
+	void insert_with_level(const float* v, const size_t new_max_layer) {
 		if (dim == 0)
 			throw std::runtime_error("antitopo_index: dim not set");
 		const size_t v_index = size();
 		vectors.insert(vectors.end(), v, v + dim);
 		visited.push_back(0);
 		const float* q = row(v_index);
-		const size_t new_max_layer =
-		    (size_t)std::floor(-std::log(gen.uniform01()) * 1 / std::log(double(conf.M)));
 		hadj_flat_with_lengths.emplace_back(new_max_layer + 1);
 		std::vector<std::vector<edge>> kNN_per_layer;
 		if (size() > 1) {
@@ -518,6 +519,82 @@ struct antitopo_index {
 			}
 		}
 		visited.assign(n, 0);
+	}
+
+	// ---- fixed-stride adjacency arrays, the batched GPU builder's view (expann_graph_build_batched) --
+	struct strided_graph {
+		size_t n = 0, U = 0, n_upper_layers = 0, stride0 = 0, strideu = 0;
+		std::vector<uint8_t> levels;      // [n]
+		std::vector<int32_t> upper_idx;   // [n] row in the upper arrays or -1
+		std::vector<uint32_t> ids0, deg0, idsu, degu;
+		std::vector<float> d0, du;
+	};
+	// rows of the vertices built so far + empty rows for `new_levels.size()` vertices to come
+	strided_graph to_strided(const std::vector<uint8_t>& new_levels, size_t slack) const {
+		strided_graph g;
+		const size_t built = size();
+		g.n = built + new_levels.size();
+		g.levels.resize(g.n);
+		for (size_t v = 0; v < built; ++v)
+			g.levels[v] = (uint8_t)(hadj_flat_with_lengths[v].size() - 1);
+		std::copy(new_levels.begin(), new_levels.end(), g.levels.begin() + built);
+		size_t lmax = max_layer ? max_layer - 1 : 0;
+		g.upper_idx.assign(g.n, -1);
+		for (size_t v = 0; v < g.n; ++v) {
+			lmax = std::max<size_t>(lmax, g.levels[v]);
+			if (g.levels[v] >= 1)
+				g.upper_idx[v] = (int32_t)g.U++;
+		}
+		g.n_upper_layers = lmax;
+		g.stride0 = conf.M0 + slack;
+		g.strideu = conf.M + slack;
+		g.ids0.assign(g.n * g.stride0, 0);
+		g.d0.assign(g.n * g.stride0, 0.0f);
+		g.deg0.assign(g.n, 0);
+		g.idsu.assign(g.U * g.n_upper_layers * g.strideu, 0);
+		g.du.assign(g.U * g.n_upper_layers * g.strideu, 0.0f);
+		g.degu.assign(g.U * g.n_upper_layers, 0);
+		for (size_t v = 0; v < built; ++v)
+			for (size_t l = 0; l < hadj_flat_with_lengths[v].size(); ++l) {
+				const auto& el = hadj_flat_with_lengths[v][l];
+				const size_t st = l == 0 ? g.stride0 : g.strideu;
+				if (el.size() > st)
+					throw std::runtime_error("antitopo_index: adjacency row longer than its stride");
+				uint32_t* ids = l == 0 ? &g.ids0[v * st] : &g.idsu[((l - 1) * g.U + (size_t)g.upper_idx[v]) * st];
+				float* ds = l == 0 ? &g.d0[v * st] : &g.du[((l - 1) * g.U + (size_t)g.upper_idx[v]) * st];
+				for (size_t i = 0; i < el.size(); ++i) {
+					ids[i] = (uint32_t)el[i].second;
+					ds[i] = el[i].first;
+				}
+				(l == 0 ? g.deg0[v] : g.degu[(l - 1) * g.U + (size_t)g.upper_idx[v]]) = (uint32_t)el.size();
+			}
+		return g;
+	}
+	// adopt the arrays the batched builder filled (all n vertices; `rows` = the vectors of the new ones)
+	void from_strided(const strided_graph& g, const float* new_rows, size_t new_max_layer, size_t new_start) {
+		const size_t built = size();
+		vectors.insert(vectors.end(), new_rows, new_rows + (g.n - built) * dim);
+		hadj_flat_with_lengths.assign(g.n, {});
+		hadj_flat.assign(g.n, {});
+		for (size_t v = 0; v < g.n; ++v) {
+			const size_t nl = (size_t)g.levels[v] + 1;
+			hadj_flat_with_lengths[v].resize(nl);
+			hadj_flat[v].resize(nl);
+			for (size_t l = 0; l < nl; ++l) {
+				const size_t st = l == 0 ? g.stride0 : g.strideu;
+				const uint32_t* ids = l == 0 ? &g.ids0[v * st] : &g.idsu[((l - 1) * g.U + (size_t)g.upper_idx[v]) * st];
+				const float* ds = l == 0 ? &g.d0[v * st] : &g.du[((l - 1) * g.U + (size_t)g.upper_idx[v]) * st];
+				const uint32_t deg = l == 0 ? g.deg0[v] : g.degu[(l - 1) * g.U + (size_t)g.upper_idx[v]];
+				auto& el = hadj_flat_with_lengths[v][l];
+				el.resize(deg);
+				for (uint32_t i = 0; i < deg; ++i)
+					el[i] = edge(ds[i], (size_t)ids[i]);
+				update_edges(l, v);
+			}
+		}
+		visited.assign(g.n, 0);
+		max_layer = new_max_layer;
+		starting_vertex = new_start;
 	}
 
 	// ---- CSR for the device: layer-major offsets; ids are 32-bit row numbers ---------------

@@ -70,6 +70,45 @@ struct gpu_antitopo_engine : public ann_engine<T, gpu_antitopo_engine<T>> {
 			row[i] = float(v.at(i));
 		index.insert(row.data());
 	}
+	// Extension: `n` rows through the batched GPU builder (expann_graph_build_batched,
+	// csrc/graph_build.hpp).  The first rows of an empty engine -- until n_serial are stored -- go
+	// through the serial restatement and seed the batches; level draws stay the reference's sequence.
+	// Returns the builder's statistics {batches, dropped reverse edges, rows re-pruned, 0}.
+	std::vector<uint64_t> store_rows_batched(const float* rows, size_t n, size_t n_serial = 2048, size_t max_batch = 0) {
+		std::vector<uint64_t> stats(4, 0);
+		if (conf.read_index || n == 0)
+			return stats;
+		if (index.dim == 0)
+			throw std::runtime_error("gpu_antitopo_engine: dimension not set");
+		if (conf.ortho_count != 1) {  // (several ortho entry points: serial path only)
+			for (size_t i = 0; i < n; ++i)
+				index.insert(rows + i * index.dim);
+			return stats;
+		}
+		std::vector<uint8_t> lv(n);
+		for (size_t i = 0; i < n; ++i)
+			lv[i] = (uint8_t)std::min<size_t>(index.draw_level(), 250);
+		size_t i = 0;
+		for (; i < n && index.size() < n_serial; ++i)
+			index.insert_with_level(rows + i * index.dim, lv[i]);
+		if (i == n)
+			return stats;
+		const size_t built = index.size();
+		auto g = index.to_strided(std::vector<uint8_t>(lv.begin() + i, lv.end()), 64);
+		std::vector<float> all(index.vectors);
+		all.insert(all.end(), rows + i * index.dim, rows + n * index.dim);
+		uint32_t ml = (uint32_t)index.max_layer, sv = (uint32_t)index.starting_vertex;
+		int rc = expann_graph_build_batched(int(index.dim), conf.device, all.data(), g.n, g.levels.data(), built, &ml, &sv,
+		                                    conf.M, conf.M0, conf.ef_construction, conf.prune_overflow,
+		                                    conf.ortho_factor, conf.ortho_bias, max_batch, g.ids0.data(), g.d0.data(),
+		                                    g.deg0.data(), g.stride0, g.upper_idx.data(), g.U, g.n_upper_layers,
+		                                    g.idsu.data(), g.du.data(), g.degu.data(), g.strideu, stats.data());
+		if (rc != EXPANN_OK)
+			throw std::runtime_error(std::string("expann_graph_build_batched: ") + expann_graph_last_error(nullptr));
+		std::vector<float>().swap(all);
+		index.from_strided(g, rows + i * index.dim, ml, sv);
+		return stats;
+	}
 	void _build() {  // :467-493
 		if (conf.write_index && !conf.index_filename.empty())
 			index.write_index(conf.index_filename);

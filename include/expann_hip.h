@@ -203,6 +203,24 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 /* device time of the last expann_graph_search's traversal kernel, milliseconds */
 double expann_graph_last_kernel_ms(const expann_graph* g);
 
+/* GPU-assisted batched construction of the graph (csrc/graph_build.hpp; replaces the inner loop of
+ * antitopo_engine::_store_vector / prune_edges, src/antitopo_engine.h:263-465, for the vectors
+ * [n_built, n) -- the first n_built come with their rows already built, by the serial host builder
+ * of include/expann/antitopo_index.h).  Vectors are inserted in BATCHES against the graph of the
+ * vectors before them: ef_construction searches per layer, prune_edges' rule on the candidate lists,
+ * reverse edges, and one more prune of every row that outgrew M / M0.  `levels[v]` = the level the
+ * reference's draw gives vertex v (:323).  Adjacency arrays are host memory, fixed row strides:
+ * layer 0 ids0 / d0 [n][stride0] + deg0[n]; layers 1.. idsu / du [(l-1) * U + upper_idx[v]][strideu] +
+ * degu, upper_idx[v] = -1 for level-0 vertices.  On return rows hold at most M0 / M edges (id,
+ * reference-order distance).  stats[4] (optional): batches, reverse edges dropped for want of slack,
+ * rows re-pruned, 0.  ortho_count = 1 only (the reference's sweep, src/bench_runner.h:138). */
+int expann_graph_build_batched(int dim, int device, const float* vectors, size_t n, const uint8_t* levels,
+                               size_t n_built, uint32_t* max_layer_io, uint32_t* starting_vertex_io, size_t M,
+                               size_t M0, size_t ef_construction, size_t prune_overflow, float ortho_factor,
+                               float ortho_bias, size_t max_batch, uint32_t* ids0, float* d0, uint32_t* deg0,
+                               size_t stride0, const int32_t* upper_idx, size_t U, size_t n_upper_layers,
+                               uint32_t* idsu, float* du, uint32_t* degu, size_t strideu, uint64_t* stats);
+
 /* the whole graph engine behind one handle (what src/pyrunner.cpp:56-90 binds: ctor,
  * store_vector / store_many_vectors, build, query_k, set_ef_search).  Construction runs on the
  * host (include/expann/antitopo_index.h), queries on the GPU (expann_graph_search). */
@@ -215,6 +233,9 @@ int expann_antitopo_create(int dim, int device, size_t M, size_t ef_construction
 void expann_antitopo_destroy(expann_antitopo* e);
 const char* expann_antitopo_last_error(const expann_antitopo* e);
 int expann_antitopo_store(expann_antitopo* e, const float* rows, size_t n);  /* _store_vector x n */
+/* the same rows through the batched GPU builder (expann_graph_build_batched); the first
+ * min(n_serial, n) of an empty engine are still inserted serially and seed the batches */
+int expann_antitopo_store_batched(expann_antitopo* e, const float* rows, size_t n, size_t n_serial);
 int expann_antitopo_build(expann_antitopo* e);                               /* _build (:467-493) */
 int expann_antitopo_set_ef_search(expann_antitopo* e, size_t ef_search);     /* :189-195 */
 /* query_k for a batch; ef_search defaults to k * ef_search_mult and is sticky (:858-859) */

@@ -66,7 +66,7 @@ def main():
         g = glob.glob(os.path.join(src, pattern))
         return g[0] if g else None
 
-    for run in ("c2", "m1", "d960"):
+    for run in ("c2", "m1", "d960", "k100", "c5"):
         st = one(f"{run}_trace/*/*_kernel_stats.csv")
         tr = one(f"{run}_trace/*/*_kernel_trace.csv")
         if not st:

@@ -74,3 +74,44 @@ def read_index_degrees(path):
     assert pos == len(raw)
     return dict(M=M, M0=M0, ef_construction=efc, prune_overflow=po, max_layer=max_layer, n=n,
                 starting_vertex=sv), deg0
+
+
+def read_index_edges(path):
+    """(header, layers): layers[v][l] = (ids uint64[], dists float32[]) of an index file in the
+    reference's layout (src/antitopo_engine.h:932-991)."""
+    import struct
+    raw = open(path, "rb").read()
+    pos = 0
+
+    def take(fmt):
+        nonlocal pos
+        v = struct.unpack_from("<" + fmt, raw, pos)
+        pos += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+    sv, M, M0, efm = take("QQQQ")
+    if take("B"):
+        take("Q")
+    efc, oc = take("QQ")
+    take("ff")
+    po = take("Q")
+    take("BB")
+    max_layer = take("Q")
+    n = take("Q")
+    for _ in range(n):
+        ln = take("Q")
+        pos += 4 * ln
+    nv = take("Q")
+    rec = np.dtype([("d", "<f4"), ("id", "<u8")])
+    layers = []
+    for v in range(nv):
+        nl = take("Q")
+        per = []
+        for layer in range(nl):
+            ne = take("Q")
+            a = np.frombuffer(raw, dtype=rec, count=ne, offset=pos)
+            pos += 12 * ne
+            per.append((a["id"].copy(), a["d"].copy()))
+        layers.append(per)
+    assert pos == len(raw)
+    return dict(M=M, M0=M0, ef_construction=efc, prune_overflow=po, max_layer=max_layer, n=n,
+                starting_vertex=sv), layers

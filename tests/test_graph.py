@@ -143,3 +143,59 @@ def test_python_module_surface(tmp_path, oracle):
     assert "M0" in eng.param_list() and int(eng.param_list()["num_distcomps"]) > 0
     eng.close()
     eng2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,efc,po", [(16, 100, 0), (60, 480, 1)])
+def test_batched_gpu_builder_makes_a_valid_graph_of_the_same_quality(tmp_path, oracle, M, efc, po):
+    """expann_graph_build_batched (csrc/graph_build.hpp) against the serial host restatement on the
+    same rows: structural invariants of the index it writes (degrees within M / M0, no self loops, no
+    duplicate edges, edge lengths = the reference-order distance of their endpoints bit for bit,
+    every vertex reachable on layer 0), recall of the oracle's walk within a few points of the serial
+    graph's, and the GPU traversal of the batched graph identical to the oracle's walk on it."""
+    from graph_helpers import read_index_edges
+    n, d, m, k = 12000, 128, 200, 10
+    common = ["--n", n, "--m", m, "--d", d, "--k", k, "--M", M, "--ef_construction", efc, "--prune_overflow", po,
+              "--data", "sift", "--build-only", 1]
+    idx_b, idx_s, qf = tmp_path / "b.index", tmp_path / "s.index", tmp_path / "q.bin"
+    lb = _tool(*common, "--batched", 1024, "--index", idx_b, "--queries", qf)
+    assert lb[0]["builder"] == "batched gpu" and lb[0]["batches"] >= 10 and lb[0]["n"] == n
+    assert lb[0]["dropped_reverse_edges"] == 0
+    hdr, layers = read_index_edges(str(idx_b))
+    gb = oracle.Graph(str(idx_b))
+    vec = gb.vectors()
+    cap = {0: 2 * M}
+    seen0 = np.zeros(n, dtype=bool)
+    for v, per_layer in enumerate(layers):
+        for l, (ids, ds) in enumerate(per_layer):
+            assert len(ids) <= cap.get(l, M), (v, l, len(ids))
+            assert v not in ids and len(set(ids.tolist())) == len(ids)
+            assert ids.max(initial=0) < n
+            if l == 0:
+                seen0[ids] = True
+    assert seen0.all(), "a vertex without an incoming layer-0 edge"
+    rng = np.random.RandomState(1)
+    for v in rng.randint(0, n, 200):
+        ids, ds = layers[v][0]
+        ref = np.array([oracle.l2_f32(vec[v], vec[j]) for j in ids], dtype=np.float32)
+        assert np.array_equal(ref.view(np.uint32), ds.view(np.uint32)), v
+    q = np.fromfile(qf, dtype=np.float32).reshape(m, d)
+    gt, _ = oracle.brute_force(vec, q, k)
+    # the serial graph on the same rows (same generator seed): quality reference
+    if M <= 16:
+        _tool(*common, "--index", idx_s)
+        gs = oracle.Graph(str(idx_s))
+        for ef in (10, 60):
+            rb = oracle.recall(gb.query_k(q, k, ef)[0], gt)
+            rs = oracle.recall(gs.query_k(q, k, ef)[0], gt)
+            assert rb > rs - 0.03, (ef, rb, rs)
+    else:
+        assert oracle.recall(gb.query_k(q, k, 60)[0], gt) > 0.9
+    from expann_amd import AntitopoEngine
+    eng = AntitopoEngine(M, efc, 1, po, False, dim=d)
+    eng.load_index(idx_b)
+    eng.set_ef_search(40)
+    ids, dists = eng.query_many(q, k)
+    oids, od, _ = gb.query_k(q, k, 40)
+    assert np.array_equal(ids, oids) and np.array_equal(dists.view(np.uint32), od.view(np.uint32))
+    eng.close()
