@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c4"],
                     help="preset: c2 = BASELINE configs[1] (default, the headline metric); "
                          "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric); "
-                         "c4 = configs[3] graph search recall sweep (SIFT-like stand-in, "
-                         "--n rows, built on the host CPU first)")
+                         "c4 = configs[3] graph search recall sweep (SIFT-like stand-in, --rows rows, "
+                         "M=60 / M0=120 / ef_construction=480, built by the batched GPU builder)")
     ap.add_argument("--query-tile", type=int, default=0)
     ap.add_argument("--row-shards", type=int, default=0,
                     help="row shards of the rank grid (default: --gpus = pure row sharding, every rank "
@@ -201,29 +201,36 @@ def profiled_traffic(kernel_name):
 
 def bench_c4(a):
     """configs[3]: antitopo graph search, GPU candidate scoring + queues inside the traversal,
-    recall@k sweep over ef_search.  SIFT1M is not available offline: SIFT-like synthetic rows
-    (SURVEY 8d).  The graph is built by the host-side builder (the reference builds on the CPU
-    too and caches index files); the timed part is the batched query launch."""
+    recall@k sweep over ef_search in the reference's own configuration (src/bench_runner.h:133-162:
+    M = 60, M0 = 120, ef_construction = 480, ef_search = k x {1..6}, both compression modes).
+    SIFT1M is not available offline: SIFT-like synthetic rows.  The graph is built by the
+    batched GPU builder (csrc/graph_build.hpp; the first rows by the serial host restatement); the
+    timed part is the batched query launch.  The GPU walk is checked against the oracle's walk of the
+    same index file on a sample of the queries (ids and distance bits)."""
     import subprocess
     import numpy as np
     tool = os.path.join(ROOT, "expann_amd", "host", "expann_graph_tool")
     import atexit
     import shutil
     import tempfile
-    out_dir = tempfile.mkdtemp(prefix="expann_c4_")   # index + query files: tens of MB, scratch only
+    out_dir = tempfile.mkdtemp(prefix="expann_c4_")   # index + query + result files: scratch only
     atexit.register(shutil.rmtree, out_dir, ignore_errors=True)
-    n = a.n if a.n != 1_000_000 else 20_000
-    idx, qf = os.path.join(out_dir, "c4.index"), os.path.join(out_dir, "c4.queries")
+    n = a.n
+    M, efc = 60, 480
+    idx, qf, rf = (os.path.join(out_dir, x) for x in ("c4.index", "c4.queries", "c4.results"))
     efs = [a.k * mult for mult in (1, 2, 3, 4, 5, 6)]       # src/bench_runner.h:134
-    cmd = [tool, "--n", str(n), "--m", str(a.m), "--d", str(a.d), "--k", str(a.k), "--M", "16",
-           "--ef_construction", "100", "--data", "sift", "--index", idx, "--queries", qf,
-           "--ef", ",".join(map(str, efs))]
-    t0 = time.perf_counter()
-    res = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    cmd = [tool, "--n", str(n), "--m", str(a.m), "--d", str(a.d), "--k", str(a.k), "--M", str(M),
+           "--ef_construction", str(efc), "--data", "sift", "--index", idx, "--queries", qf, "--results", rf,
+           "--ef", ",".join(map(str, efs)), "--batched", "1024"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        print(res.stderr[-2000:], file=sys.stderr)
+        sys.exit(res.returncode)
     lines = [json.loads(x) for x in res.stdout.strip().splitlines()]
     build = lines[0]
     sweep = [x for x in lines if x["phase"] == "query"]
-    best = max((x for x in sweep if x["use_compression"] == 0), key=lambda x: x["recall"])
+    fp32 = [x for x in sweep if x["use_compression"] == 0]
+    best = max(fp32, key=lambda x: x["recall"])
     gather_bytes = best["distcomps_per_query"] * a.d * 4 * a.m
     ach = gather_bytes / (best["kernel_ms"] * 1e-3) / 1e9
     out = {"metric": f"queries/sec at recall@{a.k} (graph search sweep), {n}xd{a.d} fp32 SIFT-like, k={a.k}",
@@ -231,28 +238,51 @@ def bench_c4(a):
            "steps": 1, "warmup": 1, "ms_per_step": round(best["time_per_query_ns"] * a.m / 1e6, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": f"antitopo_engine graph search N={n} d={a.d}, M=16 M0=32 "
-                                  f"ef_construction=100, {a.m} batched queries, k={a.k} "
+           "config": {"workload": f"antitopo_engine graph search N={n} d={a.d}, M={M} M0={2 * M} "
+                                  f"ef_construction={efc}, {a.m} batched queries, k={a.k} "
                                   "(BASELINE configs[3], SIFT-like stand-in)",
                       "recall": best["recall"], "ef_search": best["ef_search"],
-                      "build_s": round(build["time_to_build_ns"] / 1e9, 1), "sweep": sweep},
+                      "build_s": round(build["time_to_build_ns"] / 1e9, 1), "builder": build.get("builder"),
+                      "build_stats": {k: build.get(k) for k in ("batches", "dropped_reverse_edges", "rows_repruned")},
+                      "sweep": sweep},
            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "graph_search<128,fp32>", "kernel_ms": best["kernel_ms"],
+                        "kernel": f"graph_search<{a.d},fp32>", "kernel_ms": best["kernel_ms"],
                         "note": "random 512-B row gathers: latency-bound, not bandwidth-bound; "
                                 "algorithmic bytes = distcomps x d x 4 (SURVEY 8d)"}}
-    if not a.no_cpu_baseline:
+    rc = 0
+    if not a.no_cpu_baseline or not a.no_verify:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_ctypes as oc
         g = oc.Graph(idx)
-        q = np.fromfile(qf, dtype=np.float32).reshape(-1, a.d)[:200]
+        nq = min(200, a.m)
+        q = np.fromfile(qf, dtype=np.float32).reshape(-1, a.d)[:nq]
         t1 = time.perf_counter()
-        g.query_k(q, a.k, int(best["ef_search"]))
+        oids, od, odc = g.query_k(q, a.k, int(best["ef_search"]))
         dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(len(q) / dt, 1), "unit": "queries/s", "cores": 1,
-                               "kind": "port", "sample": f"{len(q)} queries, same index, same "
-                               f"ef_search={best['ef_search']} (oracle restatement of _query_k)"}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = {"value": round(len(q) / dt, 1), "unit": "queries/s", "cores": 1,
+                                   "kind": "port", "sample": f"{len(q)} queries, same index, same "
+                                   f"ef_search={best['ef_search']} (oracle restatement of _query_k)"}
+        if not a.no_verify:
+            # results file: per (compression, ef): ids m*k u64, dists m*k f32, distcomps m u32
+            per = a.m * a.k * 12 + a.m * 4
+            pos = [x["ef_search"] for x in fp32].index(best["ef_search"]) * per
+            raw = np.fromfile(rf, dtype=np.uint8)
+            ids = raw[pos:pos + a.m * a.k * 8].view(np.uint64).reshape(a.m, a.k)[:nq]
+            dd = raw[pos + a.m * a.k * 8:pos + a.m * a.k * 12].view(np.float32).reshape(a.m, a.k)[:nq]
+            exact = bool(np.array_equal(ids, oids)) and bool(np.array_equal(dd.view(np.uint32), od.view(np.uint32)))
+            out["verified_queries"] = nq
+            out["bit_exact"] = exact
+            out["recall_measured"] = best["recall"]
+            out["verified_against"] = ("oracle/expann_oracle_graph.c (CPU restatement of src/antitopo_engine.h:853-928) "
+                                       "walking the same index file; recall vs the exact brute-force answer")
+            if not exact:
+                print("bench: GPU graph walk DIFFERS from the oracle's", file=sys.stderr)
+                rc = 4
     print(json.dumps(out), flush=True)
+    if rc:
+        sys.exit(rc)
 
 
 def main():

@@ -140,9 +140,11 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 	    (n_edges && hipMemcpy(g->d_neighbours, neighbours, n_edges * sizeof(uint32_t),
 	                          hipMemcpyHostToDevice) != hipSuccess))
 		return bail("hipMemcpy");
-	// one visited array per resident workgroup; bounded to ~1/8 of a 288 GB HBM
+	// one visited array per workgroup of the (persistent) search grid; bounded to ~1/8 of a 288 GB
+	// HBM.  The walk is a chain of dependent memory round trips: what hides them is waves per CU
+	// (the kernel needs ~60 VGPRs and ~10 KB of LDS at ef = 60: 16 workgroups fit a CU).
 	const int cus = num_cus(device);
-	uint64_t slots = (uint64_t)cus * 8;
+	uint64_t slots = (uint64_t)cus * 16;
 	while (slots > 64 && slots * n > (32ull << 30))
 		slots /= 2;
 	g->slots = (uint32_t)slots;
@@ -406,8 +408,10 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 	std::vector<int32_t> up_slot;
 	size_t b0 = n_built;
 	while (b0 < n) {
-		// a batch: at most 1/8 of the graph so far; a vertex that opens a new layer goes alone
-		size_t b1 = std::min(n, b0 + std::min(max_batch, std::max<size_t>(1, b0 / 8)));
+		// a batch: at most 1/16 of the graph so far (its members do not see each other: measured
+		// recall@10 at ef = 10, 12 k rows, M = 16: serial 0.384, batches of 1/8 0.354); a vertex that
+		// opens a new layer goes alone
+		size_t b1 = std::min(n, b0 + std::min(max_batch, std::max<size_t>(1, b0 / 16)));
 		for (size_t v = b0; v < b1; ++v)
 			if (levels[v] >= max_layer) {
 				b1 = v == b0 ? v + 1 : v;

@@ -193,12 +193,35 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildSearchParams p) {
 					n_list += (uint32_t)__builtin_popcountll(mask);
 				}
 				__syncthreads();
-				for (uint32_t i0 = 0; i0 < n_list; i0 += 4) {
-					const uint32_t i = i0 + rg;
-					const uint32_t nb = nlist[i < n_list ? i : n_list - 1];
-					const float d = dist_f32(nb);
-					if (l == 0 && i < n_list)
-						ndist[i] = d;
+				for (uint32_t i0 = 0; i0 < n_list; i0 += 16) {  // 4 steps' rows in flight (graph_search.hpp)
+					constexpr int U = 4;
+					uint32_t nbu[U];
+					float r[U][DPL];
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const uint32_t i = i0 + 4 * u + rg;
+						nbu[u] = nlist[i < n_list ? i : n_list - 1];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const float* src = p.g.vec + (size_t)nbu[u] * D + l;
+#pragma unroll
+						for (int t = 0; t < DPL; ++t)
+							r[u][t] = src[16 * t];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						float acc = 0.0f;
+#pragma unroll
+						for (int t = 0; t < DPL; ++t) {
+							const float diff = q[t] - r[u][t];
+							acc = __builtin_fmaf(diff, diff, acc);
+						}
+						const float d = reduce16_ref_order(acc);
+						const uint32_t i = i0 + 4 * u + rg;
+						if (l == 0 && i < n_list)
+							ndist[i] = d;
+					}
 				}
 				__syncthreads();
 				if (lane == 0) {

@@ -254,13 +254,62 @@ __global__ __launch_bounds__(64) void graph_search_kernel(GraphSearchParams p) {
 				n_list += (uint32_t)__builtin_popcountll(mask);
 			}
 			__syncthreads();
-			// score them, 4 rows per step (:636-689 / :795-835)
-			for (uint32_t i0 = 0; i0 < n_list; i0 += 4) {
-				const uint32_t i = i0 + rg;
-				const uint32_t nb = nlist[i < n_list ? i : n_list - 1];
-				const float d = COMPRESSED ? dist_u8(nb) : dist_f32(nb);
-				if (l == 0 && i < n_list)
-					ndist[i] = d;
+			// score them (:636-689 / :795-835): 4 rows per step (16 lanes each), 4 steps' rows requested
+			// before the first is consumed -- a hop is a dependent chain of HBM round trips otherwise
+			// (30 steps x ~1 us at M0 = 120)
+			for (uint32_t i0 = 0; i0 < n_list; i0 += 16) {
+				constexpr int U = 4;
+				uint32_t nb[U];
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					const uint32_t i = i0 + 4 * u + rg;
+					nb[u] = nlist[i < n_list ? i : n_list - 1];
+				}
+				float d[U];
+				if (COMPRESSED) {
+					int b[U][NW];
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const int* r = reinterpret_cast<const int*>(p.compressed + (size_t)nb[u] * D) + l * NW;
+#pragma unroll
+						for (int w = 0; w < NW; ++w)
+							b[u][w] = r[w];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						int bself = 0;
+#pragma unroll
+						for (int w = 0; w < NW; ++w)
+							bself = dot4<kU8L2>(b[u][w], b[u][w], bself);
+						const int part = partial_score<kU8L2, NW>(q8, b[u], bself);
+						d[u] = (float)(reduce16_i32(part) + q8self);
+					}
+				} else {
+					float r[U][DPL];
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const float* src = p.vectors + (size_t)nb[u] * D + l;
+#pragma unroll
+						for (int t = 0; t < DPL; ++t)
+							r[u][t] = src[16 * t];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						float acc = 0.0f;
+#pragma unroll
+						for (int t = 0; t < DPL; ++t) {
+							const float diff = q[t] - r[u][t];
+							acc = __builtin_fmaf(diff, diff, acc);
+						}
+						d[u] = reduce16_ref_order(acc);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					const uint32_t i = i0 + 4 * u + rg;
+					if (l == 0 && i < n_list)
+						ndist[i] = d[u];
+				}
 			}
 			distcomps += n_list;
 			__syncthreads();
