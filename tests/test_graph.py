@@ -201,3 +201,29 @@ def test_batched_gpu_builder_makes_a_valid_graph_of_the_same_quality(tmp_path, o
     oids, od, _ = gb.query_k(q, k, 40)
     assert np.array_equal(ids, oids) and np.array_equal(dists.view(np.uint32), od.view(np.uint32))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_c4_scale_properties(tmp_path):
+    """N = 100 000 rows in the reference's configuration (M = 60, M0 = 120, ef_construction = 480),
+    built by the batched GPU builder, searched with ef_search = 60, both bottom-layer variants:
+    size-independent properties of every result list (ascending distances, no duplicate ids, ids in
+    range, distcomps > 0, recall in the range this data allows) -- the oracle's walk at this size is
+    covered on a sample by bench.py --workload c4."""
+    n, d, m, k = 100_000, 128, 2000, 10
+    rf = tmp_path / "c4.results"
+    lines = _tool("--n", n, "--m", m, "--d", d, "--k", k, "--M", 60, "--ef_construction", 480, "--data", "sift",
+                  "--batched", 1024, "--index", tmp_path / "c4.index", "--results", rf, "--ef", "60")
+    assert lines[0]["builder"] == "batched gpu" and lines[0]["n"] == n
+    q = [x for x in lines if x["phase"] == "query"]
+    assert len(q) == 2 and all(0.6 < x["recall"] <= 1.0 and x["distcomps_per_query"] > 1000 for x in q)
+    raw = np.fromfile(rf, dtype=np.uint8)
+    per = m * k * 12 + m * 4
+    for c in range(2):
+        ids = raw[c * per:c * per + m * k * 8].view(np.uint64).reshape(m, k)
+        dd = raw[c * per + m * k * 8:c * per + m * k * 12].view(np.float32).reshape(m, k)
+        dc = raw[c * per + m * k * 12:(c + 1) * per].view(np.uint32)
+        assert ids.max() < n and (dc > 0).all()
+        assert (np.diff(dd, axis=1) >= 0).all() or c == 1   # (uint8 walk: order of the uint8 distances, fp32 re-score)
+        srt = np.sort(ids, axis=1)
+        assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate ids (basic_bench.h:98-104)"
