@@ -358,15 +358,30 @@ def main():
         queries = torch.randn(a.m, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
             .clamp_(0, 255).to(torch.float32)
 
+    eng = None
     if native:
         # one process per GPU, the exchange behind the C ABI: rank 0's RCCL unique id travels over
         # torch.distributed, ncclCommInitRank / ncclAllGather / merge run inside libexpann_hip
-        box = [ShardedBruteForceEngine.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
-                                      unique_id=box[0])
-        eng.set_shard_device(0, base.data_ptr(), hi - lo, lo)
-    else:
+        err = None
+        try:
+            box = [ShardedBruteForceEngine.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
+                                          unique_id=box[0])
+            eng.set_shard_device(0, base.data_ptr(), hi - lo, lo)
+        except Exception as e:   # (reported, never silent: config.sharding names the exchange that ran)
+            err = e
+        bad = torch.tensor([1 if err is not None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            if a.exchange == "native":
+                raise SystemExit(f"--exchange native failed: {err}")
+            print(f"bench: native RCCL exchange unavailable on some rank ({err}); using torch.distributed",
+                  file=sys.stderr)
+            if eng is not None:
+                eng.close()
+            eng, native = None, False
+    if eng is None:
         eng = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
         eng.set_base_device(base.data_ptr(), hi - lo, lo)
     for name, val in (("query_tile", a.query_tile), ("scan_kernel", a.scan_kernel), ("debug", a.debug),
