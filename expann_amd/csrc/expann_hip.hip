@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -56,8 +57,7 @@ struct expann_index {
 	size_t elem = 4;    // bytes per stored element
 	size_t q_elem = 4;  // bytes per query element at the ABI (f32 for F32/U8 rows, int8 for I8)
 	int int_mode = -1;  // IntMode for 8-bit rows
-	uint8_t* d_q8 = nullptr;  // U8 rows: queries truncated to uint8
-	size_t q8_bytes = 0;
+	GrowPtr<uint8_t> d_q8;  // U8 rows: queries truncated to uint8
 	std::vector<unsigned char> staging;  // store_vector() rows until build()
 	size_t n_staged = 0;
 	void* d_base = nullptr;
@@ -66,68 +66,64 @@ struct expann_index {
 	uint64_t id_offset = 0;
 	hipStream_t stream = nullptr;
 	// workspace (grown on demand)
-	uint64_t* d_cand = nullptr;
-	size_t cand_elems = 0;
-	uint32_t* d_cnt = nullptr;       // [m] + overflow word + pad
-	float* d_tau[2] = {nullptr, nullptr};
-	uint32_t* d_tau_row[2] = {nullptr, nullptr};
+	GrowPtr<uint64_t> d_cand;
+	DevPtr<uint32_t> d_cnt;          // [m_alloc]
+	DevPtr<float> d_tau[2];
+	DevPtr<uint32_t> d_tau_row[2];
 	size_t m_alloc = 0;
-	uint32_t* d_overflow = nullptr;  // [4]: overflow count
+	DevPtr<uint32_t> d_overflow;     // [4]: overflow count
 	unsigned long long* d_total = nullptr;
-	uint32_t* h_flags = nullptr;     // pinned [4]
+	PinPtr<uint32_t> h_flags;        // pinned [4]
 	// latency mode (expann_search with few queries): pinned staging [queries | ids | dists]; the
 	// select kernels store the results straight into it, so a search costs one async H2D copy of
 	// the queries, the kernels, and the flag read-back -- one host sync, no pageable copies
-	void* h_pin = nullptr;
+	PinPtr<void> h_pin;
 	bool q_in_pinned_host = false;  // (expann_search -> search_pass: d_queries is pinned host memory)
-	uint32_t* d_ticket = nullptr;  // last-workgroup counter of sample_direct_f16_kernel (0 between launches)
+	DevPtr<uint32_t> d_ticket;  // last-workgroup counter of sample_direct_f16_kernel (0 between launches)
 	size_t h_pin_bytes = 0;
-	float* d_bnorm = nullptr;        // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
-	float* d_bnorm_bf = nullptr;     // same with the bf16x3 slack
-	float* d_bnmax = nullptr;        // [2]: max of d_bnorm, max of d_bnorm_bf
-	void* d_base_split = nullptr;    // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
+	DevPtr<float> d_bnorm;           // ||b||^2 (1-eps) per row (GEMM-form scan), built lazily
+	DevPtr<float> d_bnorm_bf;        // same with the bf16x3 slack
+	DevPtr<float> d_bnmax;           // [2]: max of d_bnorm, max of d_bnorm_bf
+	DevPtr<void> d_base_split;       // [n][2][dim] bf16 hi/lo planes (bf16x3 GEMM form), lazily
 	// fp32 index whose values are all integers in [0, 255] (SIFT): searches with integer queries
 	// go through an internal uint8 engine -- exact integer scores, equal to the fp32 ones bit for
 	// bit while d * 255^2 < 2^24 -- at the 8-bit kernels' speed
 	int u8_exact = 0;                // 0 not examined, 1 yes (shadow built), -1 no
 	expann_index* u8_shadow = nullptr;
-	void* d_base_u8 = nullptr;
+	DevPtr<void> d_base_u8;
 	bool strict_u8 = false;          // (on the shadow) non-8-bit / fractional queries: hand back, no error
 	double prof_extra_ms = 0;        // scan time absorbed from the shadow
 	long opt_u8_exact = 1;
 	void* d_base_i8q = nullptr;      // padded int8 copy of an 8-bit index (uint8 rows ^ 0x80) or alias of d_base
 	bool base_i8q_owned = false;
-	int* d_bp_i8q = nullptr;         // [n padded] floor(bias/2), scan_gemm_i8q.hpp
-	void* d_log = nullptr;           // per-wave hit logs of scan_gemm_f16x ([n_logs][log_cap] x 16 B)
-	uint32_t* d_log_cnt = nullptr;   // [n_logs]
+	DevPtr<int> d_bp_i8q;            // [n padded] floor(bias/2), scan_gemm_i8q.hpp
+	DevPtr<void> d_log;              // per-wave hit logs of scan_gemm_f16x ([n_logs][log_cap] x 16 B)
+	DevPtr<uint32_t> d_log_cnt;      // [n_logs]
 	size_t log_bytes = 0, log_cnt_n = 0;
 	struct {                         // scatter_log_kernel of the scan just launched (run after its timing event)
 		uint32_t n_logs = 0, log_cap = 0, cap = 0, n_chunks = 0, n_qtiles = 0, xcd_map = 0, m = 0;
 	} pending_scatter;
-	float* d_sample = nullptr;       // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
-	size_t sample_bytes = 0;
-	void* d_q_split = nullptr;       // [m][2][dim] bf16 (or [m][dim] fp16)
-	size_t q_split_bytes = 0;
-	void* d_base_f16 = nullptr;      // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
-	float* d_bnorm_f16 = nullptr;    // [n] ||b||^2 (1-eps) - abs |b|
-	float* d_bns_f16 = nullptr;      // [n] ||b||^2 (1+eps) + abs |b|: the sampled pass's row term
-	float* d_qnrm = nullptr;         // [m_alloc] ||q||^2
+	GrowPtr<float> d_sample;         // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
+	GrowPtr<void> d_q_split;         // [m][2][dim] bf16 (or [m][dim] fp16)
+	DevPtr<void> d_base_f16;         // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
+	DevPtr<float> d_bnorm_f16;       // [n] ||b||^2 (1-eps) - abs |b|
+	DevPtr<float> d_bns_f16;         // [n] ||b||^2 (1+eps) + abs |b|: the sampled pass's row term
+	DevPtr<float> d_qnrm;            // [m_alloc] ||q||^2
 	float f16_scale = 0.0f;          // power of two; 0 = not built
 	float f16_bnmax = 0.0f;          // max ||b||^2 (host copy lives in d_bnmax[2])
-	float* d_theta = nullptr;        // [m_alloc] (int32 thetas for the 8-bit GEMM form)
-	int* d_bias_i = nullptr;         // [n] sum b^2 per row (8-bit L2 GEMM form), built lazily
-	int* d_qself = nullptr;          // [m_alloc]
-	void* d_q = nullptr;             // host-API staging
-	uint64_t* d_ids = nullptr;
-	float* d_dists = nullptr;
-	size_t io_q_bytes = 0, io_out = 0;
+	DevPtr<float> d_theta;           // [m_alloc] (int32 thetas for the 8-bit GEMM form)
+	DevPtr<int> d_bias_i;            // [n] sum b^2 per row (8-bit L2 GEMM form), built lazily
+	DevPtr<int> d_qself;             // [m_alloc]
+	GrowPtr<void> d_q;               // host-API staging
+	GrowPtr<uint64_t> d_ids;
+	GrowPtr<float> d_dists;
 	// options
 	long opt_query_tile = 0, opt_cand_capacity = 0, opt_sample_ratio = 32;
 	long opt_scan_chunks = 0;
 	// deferred check (expann_sync): flag blocks of the outstanding searches, read back into a ring
 	long opt_async = 0;
 	bool host_call = false;          // (expann_search: always the synchronous path)
-	uint32_t* h_flag_ring = nullptr; // pinned [kAsyncRing][8]
+	PinPtr<uint32_t> h_flag_ring;    // pinned [kAsyncRing][8]
 	uint32_t async_pending = 0;
 	hipStream_t async_stream = nullptr;
 	long opt_xcd_tolerance = 3;  // % of modelled cost given up for an XCD-aligned chunk count
@@ -322,39 +318,23 @@ std::vector<Level> plan_levels(size_t n, size_t k, uint32_t cap, long ratio_opt)
 }
 
 int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
-	if (m > h->m_alloc) {
-		if (h->d_cnt) hipFree(h->d_cnt);
-		if (h->d_tau[0]) hipFree(h->d_tau[0]);
-		if (h->d_tau[1]) hipFree(h->d_tau[1]);
-		if (h->d_theta) hipFree(h->d_theta);
-		if (h->d_qself) hipFree(h->d_qself);
-		if (h->d_qnrm) hipFree(h->d_qnrm);
-		h->d_qnrm = nullptr;
-		HIP_TRY(h, hipMalloc(&h->d_qnrm, sizeof(float) * m));
-		h->d_cnt = nullptr;
-		h->d_theta = nullptr;
-		h->d_qself = nullptr;
-		HIP_TRY(h, hipMalloc(&h->d_qself, sizeof(int) * m));
-		h->d_tau[0] = h->d_tau[1] = nullptr;
-		HIP_TRY(h, hipMalloc(&h->d_theta, sizeof(float) * m));
-		HIP_TRY(h, hipMalloc(&h->d_cnt, sizeof(uint32_t) * m));
-		HIP_TRY(h, hipMalloc(&h->d_tau[0], sizeof(float) * m));
-		HIP_TRY(h, hipMalloc(&h->d_tau[1], sizeof(float) * m));
-		for (int i = 0; i < 2; ++i) {
-			if (h->d_tau_row[i]) hipFree(h->d_tau_row[i]);
-			h->d_tau_row[i] = nullptr;
-			HIP_TRY(h, hipMalloc(&h->d_tau_row[i], sizeof(uint32_t) * m));
+	if (m > h->m_alloc) {  // the per-query arrays grow together
+		h->m_alloc = 0;
+		for (DevPtr<float>* b : {std::addressof(h->d_qnrm), std::addressof(h->d_theta), std::addressof(h->d_tau[0]),
+		                         std::addressof(h->d_tau[1])}) {
+			b->reset();
+			HIP_TRY(h, hipMalloc(&*b, sizeof(float) * m));
 		}
+		for (DevPtr<uint32_t>* b : {std::addressof(h->d_cnt), std::addressof(h->d_tau_row[0]),
+		                            std::addressof(h->d_tau_row[1])}) {
+			b->reset();
+			HIP_TRY(h, hipMalloc(&*b, sizeof(uint32_t) * m));
+		}
+		h->d_qself.reset();
+		HIP_TRY(h, hipMalloc(&h->d_qself, sizeof(int) * m));
 		h->m_alloc = m;
 	}
-	const size_t need = m * (size_t)cap;
-	if (need > h->cand_elems) {
-		if (h->d_cand) hipFree(h->d_cand);
-		h->d_cand = nullptr;
-		h->cand_elems = 0;
-		HIP_TRY(h, hipMalloc(&h->d_cand, sizeof(uint64_t) * need));
-		h->cand_elems = need;
-	}
+	HIP_TRY(h, h->d_cand.ensure(sizeof(uint64_t) * m * (size_t)cap));
 	if (!h->d_overflow) {
 		// flags [4 x u32] and statistics [2 x u64] share one allocation: one memset, one read-back
 		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
@@ -507,7 +487,7 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	if (!h->d_bnmax)
 		HIP_TRY(h, hipMalloc(&h->d_bnmax, 4 * sizeof(float)));
 	hipLaunchKernelGGL(convert_f16_kernel, dim3((uint32_t)std::min<size_t>((nv + kBlock - 1) / kBlock, 8192)),
-	                   dim3(kBlock), 0, st, (const float*)h->d_base, nv, scale, (_Float16*)h->d_base_f16,
+	                   dim3(kBlock), 0, st, (const float*)h->d_base, nv, scale, h->d_base_f16.as<_Float16>(),
 	                   (uint32_t*)nullptr);
 	const uint32_t blocks16 = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
 	hipLaunchKernelGGL(gf->sqnorm, dim3(blocks16), dim3(kBlock), 0, st, (const float*)h->d_base,
@@ -562,7 +542,7 @@ const GemmVariant* pick_gemm(const expann_index* h, size_t m) {
 }
 
 int ensure_bnorm(expann_index* h, const GemmVariant* gv, bool bf16, hipStream_t st) {
-	float*& dst = bf16 ? h->d_bnorm_bf : h->d_bnorm;
+	DevPtr<float>& dst = bf16 ? h->d_bnorm_bf : h->d_bnorm;
 	const uint32_t blocks = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
 	if (!dst) {
 		HIP_TRY(h, hipMalloc(&dst, sizeof(float) * h->n));
@@ -580,7 +560,7 @@ int ensure_bnorm(expann_index* h, const GemmVariant* gv, bool bf16, hipStream_t 
 		HIP_TRY(h, hipMalloc(&h->d_base_split, nv * 4));
 		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
 		                   dim3(kBlock), 0, st, (const float*)h->d_base, h->n, h->dim,
-		                   (__bf16*)h->d_base_split);
+		                   h->d_base_split.as<__bf16>());
 		HIP_TRY(h, hipGetLastError());
 	}
 	return EXPANN_OK;
@@ -755,7 +735,7 @@ int ensure_i8q(expann_index* h, const GemmI8qVariant* gq, hipStream_t st) {
 	}
 	HIP_TRY(h, hipMalloc(&h->d_bp_i8q, sizeof(int) * n_pad));
 	hipLaunchKernelGGL(i8q_bp_kernel, dim3((uint32_t)((n_pad + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-	                   st, h->int_mode != kI8IP ? (const int*)h->d_bias_i : (const int*)nullptr,
+	                   st, h->int_mode != kI8IP ? h->d_bias_i.as<const int>() : (const int*)nullptr,
 	                   (uint32_t)h->n, (uint32_t)n_pad, h->d_bp_i8q);
 	if (gq->dq != h->dim) {
 		// own copy with rows padded to dq bytes (zeros in the int8 domain), whole 64-row tiles
@@ -802,30 +782,18 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	const void* q8 = d_queries;
 	if (gq->dq != h->dim) {  // rows of the padded geometry: queries padded (and mapped) the same way
 		const size_t nb = m * (size_t)gq->dq;
-		if (nb > h->q_split_bytes) {
-			if (h->d_q_split) hipFree(h->d_q_split);
-			h->d_q_split = nullptr;
-			h->q_split_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_q_split, nb));
-			h->q_split_bytes = nb;
-		}
+		HIP_TRY(h, h->d_q_split.ensure(nb));
 		hipLaunchKernelGGL(i8q_pad_rows_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, m, (uint32_t)h->dim / 4,
 		                   (uint32_t)gq->dq / 4, m, h->int_mode == kU8L2 ? 0x80808080u : 0u,
-		                   (uint32_t*)h->d_q_split);
+		                   h->d_q_split.as<uint32_t>());
 		q8 = h->d_q_split;
 	} else if (h->int_mode == kU8L2) {  // queries ^ 0x80 (d_queries is the uint8 conversion, d_q8)
 		const size_t nb = m * (size_t)h->dim;
-		if (nb > h->q_split_bytes) {
-			if (h->d_q_split) hipFree(h->d_q_split);
-			h->d_q_split = nullptr;
-			h->q_split_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_q_split, nb));
-			h->q_split_bytes = nb;
-		}
+		HIP_TRY(h, h->d_q_split.ensure(nb));
 		hipLaunchKernelGGL(i8q_copy_xor_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, nb / 4, nb / 4, 0x80808080u,
-		                   (uint32_t*)h->d_q_split);
+		                   h->d_q_split.as<uint32_t>());
 		q8 = h->d_q_split;
 	}
 	const uint32_t nt = (uint32_t)((h->n + kF16TB - 1) / kF16TB);
@@ -850,14 +818,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			hipLaunchKernelGGL(gq->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 			                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)nullptr,
 			                   (int*)nullptr, h->d_qself);
-		const size_t need = m * (size_t)chunks * 32 * sizeof(int);
-		if (need > h->sample_bytes) {
-			if (h->d_sample) hipFree(h->d_sample);
-			h->d_sample = nullptr;
-			h->sample_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_sample, need));
-			h->sample_bytes = need;
-		}
+		HIP_TRY(h, h->d_sample.ensure(m * (size_t)chunks * 32 * sizeof(int)));
 		GemmI8qParams sp{};
 		sp.base = h->d_base_i8q;
 		sp.bp = h->d_bp_i8q;
@@ -871,21 +832,21 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		sp.n_qtiles = nqt;
 		sp.queries = q8;
 		sp.m = (uint32_t)m;
-		sp.sample_out = (int*)h->d_sample;
+		sp.sample_out = h->d_sample.as<int>();
 		sp.n_chunks = schunks;
 		if (dbg)
 			std::fprintf(stderr, "[i8q] sample: grid %u x %u, t_sel %u stride %u tpb %u chunks %u nt %u m %zu base %p bp %p q %p out %p (%zu B)\n",
 			             schunks, nqt, t_sel, sp.tile_stride, sp.tiles_per_block, schunks, nt, m, sp.base,
-			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->sample_bytes);
+			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->d_sample.bytes);
 		mark("qself");
 		hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), wg, lds, st, sp);
 		mark("sample");
 		SampleTauI8Params tp{};
-		tp.vals = (const int*)h->d_sample;
+		tp.vals = h->d_sample.as<const int>();
 		tp.n_vals = schunks * 32;
 		tp.m = (uint32_t)m;
 		tp.k = (uint32_t)k;
-		tp.thp = (int*)h->d_theta;
+		tp.thp = h->d_theta.as<int>();
 		tp.cand_cnt = h->d_cnt;
 		hipLaunchKernelGGL(tp.n_vals <= 512 ? sample_tau_i8_kernel<8>
 		                                   : (tp.n_vals <= 1024 ? sample_tau_i8_kernel<16> : sample_tau_i8_kernel<32>),
@@ -897,7 +858,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		fp.n_tiles_sel = nt;
 		fp.tile_stride = 1;
 		fp.tile_run = 1;
-		fp.thp = (const int*)h->d_theta;
+		fp.thp = h->d_theta.as<const int>();
 		fp.qself = h->d_qself;
 		fp.cand_cnt = h->d_cnt;
 		fp.cand = h->d_cand;
@@ -995,7 +956,7 @@ int build_u8_shadow(expann_index* h, hipStream_t st) {
 	}
 	HIP_TRY(h, hipMalloc(&h->d_base_u8, nv));
 	hipLaunchKernelGGL(cast_f32_u8_kernel, dim3(4096), dim3(kBlock), 0, st, (const float*)h->d_base, nv,
-	                   (uint8_t*)h->d_base_u8);
+	                   h->d_base_u8.as<uint8_t>());
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));
 	expann_index* sh = nullptr;
@@ -1007,8 +968,7 @@ int build_u8_shadow(expann_index* h, hipStream_t st) {
 	if (rc != EXPANN_OK) {
 		if (sh)
 			expann_destroy(sh);
-		hipFree(h->d_base_u8);
-		h->d_base_u8 = nullptr;
+		h->d_base_u8.reset();
 		h->u8_exact = -1;  // (not fatal: the fp32 paths serve the index)
 		return EXPANN_OK;
 	}
@@ -1021,9 +981,7 @@ void drop_u8_shadow(expann_index* h) {
 	if (h->u8_shadow)
 		expann_destroy(h->u8_shadow);
 	h->u8_shadow = nullptr;
-	if (h->d_base_u8)
-		hipFree(h->d_base_u8);
-	h->d_base_u8 = nullptr;
+	h->d_base_u8.reset();
 	h->u8_exact = 0;
 }
 // the shadow's counters and scan time become the parent's
@@ -1060,13 +1018,7 @@ int sampled_pass_f16(expann_index* h, const GemmF16Variant* gvf, size_t m, size_
                      float* d_tau, uint32_t* d_tau_row, hipStream_t st, bool* done) {
 	*done = false;
 	auto ensure_sample = [&](size_t need) -> int {
-		if (need > h->sample_bytes) {
-			if (h->d_sample) hipFree(h->d_sample);
-			h->d_sample = nullptr;
-			h->sample_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_sample, need));
-			h->sample_bytes = need;
-		}
+		HIP_TRY(h, h->d_sample.ensure(need));
 		return EXPANN_OK;
 	};
 	SampleTauParams tp{};
@@ -1234,17 +1186,15 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 			const size_t need = (size_t)n_logs * log_cap * 16;
 			if (need > h->log_bytes || n_logs > h->log_cnt_n) {
 				HIP_TRY(h, hipStreamSynchronize(st));
-				if (h->d_log) hipFree(h->d_log);
-				if (h->d_log_cnt) hipFree(h->d_log_cnt);
-				h->d_log = nullptr;
-				h->d_log_cnt = nullptr;
+				h->d_log.reset();
+				h->d_log_cnt.reset();
 				h->log_bytes = h->log_cnt_n = 0;
 				HIP_TRY(h, hipMalloc(&h->d_log, need));
 				HIP_TRY(h, hipMalloc(&h->d_log_cnt, sizeof(uint32_t) * n_logs));
 				h->log_bytes = need;
 				h->log_cnt_n = n_logs;
 			}
-			fp.log = (uint4*)h->d_log;
+			fp.log = h->d_log.as<uint4>();
 			fp.log_cnt = h->d_log_cnt;
 			fp.log_cap = log_cap;
 			fp.lost = h->d_overflow;
@@ -1276,6 +1226,493 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 	return EXPANN_OK;
 }
 
+// ---- one pass over <= kMaxQueriesPerPass queries, as a planner + steps -------------------------
+// choose_kernels()   which kernel family serves this pass (the planner: row type, metric, batch size,
+//                    options, what an earlier attempt learned) and the index's derived copies it needs
+// prepare_queries()  the query-side conversions of that family (scaled fp16 / bf16 split)
+// plan_thresholds()  threshold levels of this attempt: the ladder, class minima, or one sampled pass
+// run_level(li)      scan of level li (direct / fp32 / bf16x3 / fp16 / int8 MFMA filter) + selection
+// check(attempt)     the one host wait: flags read back, retry with larger lists / another family
+struct ScanSel {
+	ScanFn fn = nullptr;
+	int tq = 0;
+	const char* name = "";
+};
+struct SearchPass {
+	expann_index* h;
+	const void* d_queries;
+	size_t m, k;
+	uint64_t* d_ids;
+	float* d_dists;
+	hipStream_t st;
+	bool ip;
+	int cus;
+	uint32_t cap;
+	ScanSel svs;
+	const ScanSel* sv = &svs;
+	// the planner's choice
+	const GemmVariant* gv = nullptr;
+	const GemmI8Variant* gvi = nullptr;
+	const GemmBf16Variant* gvb = nullptr;
+	const GemmF16Variant* gvf = nullptr;
+	// what an attempt learned
+	bool flags_clean = false;   // the fp16 prelude has just zeroed the flag block
+	bool force_direct = false;  // a GEMM-form filter overflowed: massive near-ties
+	bool no_f16 = false;        // the queries do not fit the fp16 range of this index
+	// thresholds of the current attempt
+	std::vector<Level> levels;
+	uint32_t n_qtiles = 0;
+	size_t li_start = 0;
+	bool theta_ready = false;   // the sampled pass also wrote theta' and zeroed the list counters
+
+	enum Next { kDone, kRestart, kRetry };
+	int choose_kernels();
+	int prepare_queries(bool* restart);
+	int plan_thresholds();
+	int run_level(size_t li);
+	int check(int attempt, Next* next);
+	int run();
+};
+
+int SearchPass::choose_kernels() {
+	gv = force_direct ? nullptr : pick_gemm(h, m);
+	gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
+	gvb = nullptr;
+	gvf = nullptr;
+	if (h->opt_scan_kernel == 2 && !gv && !gvi)
+		return h->fail(EXPANN_ERR_UNSUPPORTED,
+		               "GEMM-form scan (scan_kernel=2): f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
+	if (gvi) {
+		int rc = ensure_bias_i8(h, gvi, st);
+		if (rc != EXPANN_OK)
+			return rc;
+	}
+	if (gv && h->opt_scan_kernel != 2)
+		for (const auto& v : kGemmBf16)
+			if (v.d == h->dim)
+				gvb = &v;
+	if (h->opt_scan_kernel == 3 && !gvb)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "bf16x3 GEMM-form scan: f32 L2 with dim 64 or 128 only");
+	// fp16 single-product form: default when available; a search whose queries leave the fp16
+	// range after scaling is redone with the bf16x3 form (no_f16)
+	if (gv && !no_f16 && f16_choice(h->opt_scan_kernel)) {
+		for (const auto& v : kGemmF16)
+			if (v.d == h->dim)
+				gvf = &v;
+		if (h->opt_scan_kernel == 6 || (h->opt_scan_kernel == 0 && h->opt_f16x))
+			for (const auto& v : ((h->opt_debug & ~16L) ? kGemmF16XDbg : kGemmF16X))
+				if (v.d == h->dim)
+					gvf = &v;
+	}
+	if ((h->opt_scan_kernel == 4 || h->opt_scan_kernel == 6) && !gvf && !no_f16)
+		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
+	if (gvf)
+		gvb = nullptr;
+	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))
+		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on / do not exist
+	if (gv && !gvf) {
+		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
+		if (rc != EXPANN_OK)
+			return rc;
+	}
+	return EXPANN_OK;
+}
+
+int SearchPass::prepare_queries(bool* restart) {
+	*restart = false;
+	if (gvf) {
+		int rc = ensure_f16(h, gvf, st);
+		if (rc != EXPANN_OK)
+			return rc;
+		if (h->f16_scale < 0.0f) {  // the index does not fit the fp16 range at any allowed scale
+			no_f16 = true;
+			*restart = true;
+			return EXPANN_OK;
+		}
+		rc = ensure_workspace(h, m, cap);
+		if (rc != EXPANN_OK)
+			return rc;
+		const size_t nv = m * (size_t)h->dim;
+		HIP_TRY(h, h->d_q_split.ensure(nv * 4));
+		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end):
+		// one memset of the flag block, one kernel
+		// (latency mode, one workgroup: the kernel clears the flag block itself and, when the queries
+		// still sit in pinned host memory, leaves the device copy the later kernels read)
+		const bool one_wg = m <= (size_t)kRowsPerGroup;
+		const bool from_host = h->q_in_pinned_host && one_wg;
+		if (!one_wg)
+			HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, 32, st));
+		flags_clean = true;
+		hipLaunchKernelGGL(gvf->prep, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)), dim3(kBlock),
+		                   0, st, (const float*)d_queries, (uint32_t)m, h->f16_scale, h->d_q_split.as<_Float16>(),
+		                   h->d_qnrm, h->d_overflow + 2, from_host ? h->d_q.as<float>() : (float*)nullptr,
+		                   one_wg ? h->d_overflow : (uint32_t*)nullptr);
+		HIP_TRY(h, hipGetLastError());
+		if (from_host) {
+			d_queries = h->d_q;
+			h->q_in_pinned_host = false;
+		}
+	}
+	if (gvb) {  // queries -> bf16 hi/lo planes
+		const size_t nv = m * (size_t)h->dim;
+		HIP_TRY(h, h->d_q_split.ensure(nv * 4));
+		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
+		                   dim3(kBlock), 0, st, (const float*)d_queries, m, h->dim,
+		                   h->d_q_split.as<__bf16>());
+		HIP_TRY(h, hipGetLastError());
+	}
+	return EXPANN_OK;
+}
+
+int SearchPass::plan_thresholds() {
+	int rc = ensure_workspace(h, m, cap);
+	if (rc != EXPANN_OK)
+		return rc;
+	levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
+	n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
+	if (!gv && !gvi && levels.size() >= 3 && h->opt_sample_pass) {
+		// direct path: ONE sampled level of class minima (1/16 of the rows) instead of the
+		// first two levels of the ladder -- a launch chain shorter by a scan, a select and a
+		// memset, and ~10 k instead of ~32 k candidates in the full scan
+		const uint32_t n_groups = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
+		const uint32_t sel = n_groups / 16;
+		uint32_t blocks = std::min<uint32_t>({128u, cap / 16, sel / 8});
+		if (blocks * 16 >= 8 * k && blocks >= 16) {
+			Level l0;
+			l0.n_groups_sel = sel;
+			l0.group_stride = 16;
+			l0.classmin_blocks = blocks;
+			levels.clear();
+			levels.push_back(l0);
+			levels.push_back(Level{n_groups, 1, 0});
+		}
+	}
+	if (!flags_clean) {  // overflow count and statistics (words 1, 2: uint8 / fp16 range flags, kept)
+		HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
+		HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
+	}
+	flags_clean = false;
+	// fp16 form on a large index: ONE sampled pass (1/16 of the rows, class maxima per query,
+	// scan_gemm_f16.hpp) gives the threshold of the full scan -- no direct level-0 scan, no
+	// intermediate candidate lists and selects
+	li_start = 0;
+	theta_ready = false;
+	if (gvf && h->opt_sample_pass && levels.size() >= 2) {
+		const int rs = sampled_pass_f16(h, gvf, m, k, ip, cus, h->d_tau[levels.size() & 1],
+		                                h->d_tau_row[levels.size() & 1], st, &theta_ready);
+		if (rs != EXPANN_OK)
+			return rs;
+		if (theta_ready)
+			li_start = levels.size() - 1;
+	}
+	return EXPANN_OK;
+}
+
+int SearchPass::run_level(size_t li) {
+	const Level& L = levels[li];
+	const bool first = (li == 0), last = (li + 1 == levels.size());
+	ScanParams sp{};
+	sp.base = h->d_base;
+	sp.n_rows = (uint32_t)h->n;
+	sp.n_groups_sel = L.n_groups_sel;
+	sp.group_stride = L.group_stride;
+	sp.n_qtiles = n_qtiles;
+	sp.queries = d_queries;
+	sp.m = (uint32_t)m;
+	sp.tau = first ? nullptr : h->d_tau[(li + 1) & 1];
+	sp.tau_row = first ? nullptr : h->d_tau_row[(li + 1) & 1];
+	sp.cand_cnt = h->d_cnt;
+	sp.cand = h->d_cand;
+	sp.cap = cap;
+	// ~16 workgroups per CU in total, at least 8 groups (128 rows) per workgroup
+	uint32_t target_chunks = (uint32_t)std::max<long>(1, (16L * cus + n_qtiles - 1) / n_qtiles);
+	uint32_t max_chunks = std::max<uint32_t>(1, L.n_groups_sel / 8);
+	uint32_t n_chunks = std::min(target_chunks, max_chunks);
+	if (first && L.classmin_blocks) {
+		n_chunks = L.classmin_blocks;
+		sp.classmin = 1;
+	}
+	sp.groups_per_block = (L.n_groups_sel + n_chunks - 1) / n_chunks;
+	n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
+	if (!first && !theta_ready)
+		HIP_TRY(h, hipMemsetAsync(h->d_cnt, 0, sizeof(uint32_t) * m, st));
+	const bool use_gemm = gv && !first;
+	const bool timed = last && h->profiling && h->ev_used < kEventPairs;
+	uint32_t passes = n_qtiles;
+	const char* kname = sv->name;
+	uint32_t qt_used = (uint32_t)sv->tq;
+	if (use_gemm) {
+		// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
+		const float f16_abs = gvf ? std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
+		                          : 0.0f;
+		if (gvf && theta_ready)
+			;
+		else if (gvf)
+			hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
+			                   dim3(kBlock), 0, st, h->d_qnrm.as<const float>(), (uint32_t)m,
+			                   gemm_f16_filter_eps(h->dim), f16_abs, (const float*)sp.tau,
+			                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0);
+		else
+			hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+			                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
+			                   (const float*)sp.tau,
+			                   1.0f - (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)),
+			                   h->d_theta);
+		GemmScanParams gp{};
+		gp.base = (const float*)h->d_base;
+		gp.bnorm = h->d_bnorm;
+		gp.n_rows = (uint32_t)h->n;
+		const uint32_t n_tiles = (uint32_t)((h->n + kGemmTB - 1) / kGemmTB);
+		gp.n_tiles_sel = last ? n_tiles
+		                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
+		gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
+		const uint32_t tq_wg = gvf ? (uint32_t)gvf->wgq : (gvb ? kGemmBf16TQ : kGemmTQ);
+		uint32_t tq_small = 0;
+		gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
+		gp.queries = (const float*)d_queries;
+		gp.theta = h->d_theta;
+		gp.m = (uint32_t)m;
+		gp.cand_cnt = h->d_cnt;
+		gp.cand = h->d_cand;
+		gp.cap = cap;
+		// One workgroup per CU is resident (128 KiB of LDS), so the launch runs in rounds
+		// of `cus` workgroups: pick the row-chunk count that minimises
+		// rounds x (steps per workgroup + ~2 steps of prologue).
+		uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 1024, 0, nullptr);
+		gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
+		gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
+		if (timed)
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+		if (gvf) {
+			const int rl = launch_scan_f16(h, gvf, L.n_groups_sel * kRowsPerGroup, last, m, cus, ip, cap, st, &kname,
+			                               &gp.n_qtiles, &tq_small);
+			if (rl != EXPANN_OK)
+				return rl;
+		} else if (gvb) {
+			GemmBf16Params bp{};
+			bp.base_split = h->d_base_split;
+			bp.bnorm = h->d_bnorm_bf;
+			bp.n_rows = gp.n_rows;
+			bp.n_tiles_sel = gp.n_tiles_sel;
+			bp.tile_stride = gp.tile_stride;
+			bp.tile_run = 1;
+			if (!last && gp.tile_stride >= 8) {
+				// sampled level: runs of 8 consecutive tiles (one 2 MiB page each at d=128)
+				// instead of isolated tiles, same number of tiles
+				bp.tile_run = 8;
+				bp.n_tiles_sel = (gp.n_tiles_sel / 8) * 8;
+				if (bp.n_tiles_sel == 0) {
+					bp.n_tiles_sel = gp.n_tiles_sel;
+					bp.tile_run = 1;
+				}
+			}
+			bp.tiles_per_block = gp.tiles_per_block;
+			bp.n_qtiles = gp.n_qtiles;
+			bp.queries_split = h->d_q_split;
+			bp.theta = gp.theta;
+			bp.m = gp.m;
+			bp.cand_cnt = gp.cand_cnt;
+			bp.cand = gp.cand;
+			bp.cap = gp.cap;
+			bp.debug = (uint32_t)h->opt_debug;
+			hipLaunchKernelGGL(gvb->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+			                   2 * kGemmTB * h->dim * sizeof(float), st, bp);
+			kname = gvb->name;
+		} else {
+			hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+			                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
+			kname = gv->name;
+		}
+		passes = gp.n_qtiles;
+		qt_used = tq_small ? tq_small : tq_wg;  // (launch_scan_f16 reports the tile it used)
+	} else if (gvi && !first) {
+		hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
+		                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,
+		                   h->d_theta.as<int>(), h->d_qself);
+		const uint32_t tb = (uint32_t)gemm_i8_tb(h->dim);
+		GemmI8Params gp{};
+		gp.base = h->d_base;
+		gp.bias = h->d_bias_i;
+		gp.n_rows = (uint32_t)h->n;
+		const uint32_t n_tiles = (uint32_t)((h->n + tb - 1) / tb);
+		gp.n_tiles_sel = last ? n_tiles
+		                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + tb - 1) / tb);
+		gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
+		gp.n_qtiles = (uint32_t)((m + kGemmI8TQ - 1) / kGemmI8TQ);
+		gp.queries = d_queries;
+		gp.theta = h->d_theta.as<const int>();
+		gp.qself = h->d_qself;
+		gp.m = (uint32_t)m;
+		gp.cand_cnt = h->d_cnt;
+		gp.cand = h->d_cand;
+		gp.cap = cap;
+		uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 4096, 0, nullptr);
+		gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
+		gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
+		if (timed)
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+		hipLaunchKernelGGL(gvi->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
+		                   2 * tb * h->dim, st, gp);
+		passes = gp.n_qtiles;
+		kname = gvi->name;
+		qt_used = kGemmI8TQ;
+	} else {
+		if (timed)
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+		hipLaunchKernelGGL(sv->fn, dim3(n_chunks * n_qtiles), dim3(kBlock), 0, st, sp);
+	}
+	if (timed) {
+		HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
+		h->ev_used++;
+	}
+	if (h->pending_scatter.n_logs) {  // scan_gemm_f16x: file the per-wave hit logs into the lists
+		const auto ps = h->pending_scatter;
+		h->pending_scatter.n_logs = 0;
+		// ~1024 workgroups: the logs of a (query tile, wave) pair are split over n_groups of them
+		const uint32_t want = std::max<uint32_t>(1, (1024 + ps.n_qtiles * 4 - 1) / (ps.n_qtiles * 4));
+		const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
+		const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
+		GatherLogParams gp{h->d_log.as<const uint4>(), h->d_log_cnt.as<const uint32_t>(), ps.log_cap, ps.n_chunks,
+		                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
+		hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
+	}
+	if (last && (timed || !h->profiling)) {
+		h->prof.scan_launches++;
+		h->prof.scan_rows += h->n;
+		h->prof.scan_query_tiles += passes;
+		h->prof.query_tile = qt_used;
+		h->prof.levels = (uint32_t)(levels.size() - li_start + (li_start ? 1 : 0));
+		std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", kname);
+	}
+	HIP_TRY(h, hipGetLastError());
+
+	SelectParams sel{};
+	sel.cand = h->d_cand;
+	sel.cand_cnt = first ? nullptr : h->d_cnt;
+	sel.fixed_count = (first && L.classmin_blocks) ? n_chunks * 16 : L.n_groups_sel * kRowsPerGroup;
+	sel.cap = cap;
+	sel.k = (uint32_t)k;
+	sel.id_offset = h->id_offset;
+	sel.out_ids = last ? d_ids : nullptr;
+	sel.out_dists = last ? d_dists : nullptr;
+	sel.tau_out = last ? nullptr : h->d_tau[li & 1];
+	sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
+	sel.tau_row_out = last ? nullptr : h->d_tau_row[li & 1];
+	sel.tau_row_prev = first ? nullptr : h->d_tau_row[(li + 1) & 1];
+	sel.rerank_base = use_gemm ? (const float*)h->d_base : nullptr;
+	sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
+	sel.dim = (uint32_t)h->dim;
+	sel.metric_ip = ip ? 1u : 0u;
+	// (inner product, fp16 form only: the approximate key is off by at most E_q + E_b in
+	// total, half the L2 margins)
+	const float pr = ip ? 1.0f : 2.0f;
+	sel.prune_eps = use_gemm ? (gvf ? pr * gemm_f16_filter_eps(h->dim)
+	                                : (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)))
+	                         : 0.0f;
+	sel.prune_abs = (use_gemm && gvf)
+	                    ? pr * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
+	                    : 0.0f;
+	sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
+	sel.qnrm = (use_gemm && gvf) ? h->d_qnrm : nullptr;
+	sel.overflow = h->d_overflow;
+	if (last && sel.cand_cnt && h->profiling)  // statistics: candidates of the full scan
+		hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
+		                   h->d_total);
+	if (m <= 64) {
+		sel.wave0_short = 1;  // latency mode: one launch, wave 0 orders the short lists
+	} else if (sel.rerank_base && sel.cand_cnt) {
+		// short lists (the usual case after a GEMM-form scan): one wave per query
+		launch_select_wave(sel, m, cap, st);
+	}
+	hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
+	                   sizeof(uint64_t) * cap + 16, st, sel);
+	HIP_TRY(h, hipGetLastError());
+	return EXPANN_OK;
+}
+
+int SearchPass::check(int attempt, Next* next) {
+	*next = kDone;
+	// overflow check (the only host sync of a search); flags and statistics are contiguous
+	if (defer_flags(h, st, attempt)) {  // deferred check: expann_sync reads the flags
+		float sc = gvf ? h->f16_scale : 0.0f;  // (fp16 form: the range check of max |q| needs the scale)
+		std::memcpy(&h->h_flag_ring[8 * (h->async_pending - 1) + 6], &sc, sizeof(float));
+		return EXPANN_OK;
+	}
+	HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
+	                          hipMemcpyDeviceToHost, st));
+	HIP_TRY(h, hipStreamSynchronize(st));
+	unsigned long long tot;
+	std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
+	h->prof.candidates = tot;
+	if (gvf) {  // queries outside the fp16 range of this index: redo with the bf16x3 form
+		float qmax;  // bit pattern of max |q| (flags word 2, read back with the overflow flags)
+		std::memcpy(&qmax, &h->h_flags[2], sizeof(float));
+		if (!(qmax * h->f16_scale <= 60000.0f)) {
+			no_f16 = true;
+			h->prof.retries++;
+			*next = kRestart;
+			return EXPANN_OK;
+		}
+	}
+	if (h->strict_u8 && (h->h_flags[1] != 0 || h->h_flags[3] != 0))
+		return kStrictReject;
+	if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
+		return h->fail(EXPANN_ERR_UNSUPPORTED,
+		               std::to_string(h->h_flags[1]) +
+		                   " query values outside [0,255]: the uint8 metric "
+		                   "(dist2_compressed) is only defined for 8-bit valued queries");
+	if (h->h_flags[0] == 0)
+		return EXPANN_OK;
+	// some candidate list overflowed: retry with 4x the capacity
+	h->prof.retries++;
+	if (gvf && gvf->hit_log)  // (or a hit log / queue of the 16x16x32 form: the direct appends have no such limit)
+		for (const auto& v : kGemmF16)
+			if (v.d == h->dim)
+				gvf = &v;
+	if ((cap >= kMaxCap || attempt >= 3) && (gv || gvi) && h->opt_scan_kernel == 0) {
+		// the GEMM forms cannot break exact ties by row number; the direct scan can
+		force_direct = true;
+		*next = kRestart;
+		return EXPANN_OK;
+	}
+	if (cap >= kMaxCap || attempt >= 3)
+		return h->fail(EXPANN_ERR_OVERFLOW,
+		               "candidate lists overflowed (" + std::to_string(h->h_flags[0]) +
+		                   " queries) at capacity " + std::to_string(cap) +
+		                   "; the data has more near-ties than the threshold filter supports");
+	cap = std::min(cap * 4, kMaxCap);
+	*next = kRetry;
+	return EXPANN_OK;
+}
+
+int SearchPass::run() {
+	for (;;) {  // (a restart: another kernel family serves the same queries)
+		int rc = choose_kernels();
+		if (rc != EXPANN_OK)
+			return rc;
+		bool restart = false;
+		rc = prepare_queries(&restart);
+		if (rc != EXPANN_OK)
+			return rc;
+		if (restart)
+			continue;
+		Next next = kDone;
+		for (int attempt = 0;; ++attempt) {  // (a retry: the same family with larger candidate lists)
+			rc = ensure_workspace(h, m, cap);
+			if (rc == EXPANN_OK)
+				rc = plan_thresholds();
+			for (size_t li = li_start; rc == EXPANN_OK && li < levels.size(); ++li)
+				rc = run_level(li);
+			if (rc == EXPANN_OK)
+				rc = check(attempt, &next);
+			if (rc != EXPANN_OK || next != kRetry)
+				break;
+		}
+		if (rc != EXPANN_OK || next == kDone)
+			return rc;
+	}
+}
+
 // One pipeline pass over <= kMaxQueriesPerPass queries (device pointers).
 int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint64_t* d_ids,
                 float* d_dists, hipStream_t st) {
@@ -1299,35 +1736,24 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 				return h->fail(rq, h->u8_shadow->err);
 		}
 	}
-	struct {
-		ScanFn fn;
-		int tq;
-		const char* name;
-	} svs{nullptr, 0, ""};
+	ScanSel svs;
 	if (h->dtype == EXPANN_DTYPE_F32) {
 		const ScanVariant* v = pick_scan_f32(h->dim, ip, m, h->opt_query_tile);
 		if (v)
-			svs = {v->fn, v->tq, v->name};
+			svs = ScanSel{v->fn, v->tq, v->name};
 	} else {
 		const ScanI8Variant* v = pick_scan_i8(h->dim, h->int_mode, m, h->opt_query_tile);
 		if (v)
-			svs = {v->fn, v->tq, v->name};
+			svs = ScanSel{v->fn, v->tq, v->name};
 	}
 	if (!svs.fn)
 		return h->fail(EXPANN_ERR_UNSUPPORTED,
 		               "no scan kernel for dim " + std::to_string(h->dim) +
 		                   " / query_tile " + std::to_string(h->opt_query_tile));
-	const auto* sv = &svs;
 	if (h->dtype == EXPANN_DTYPE_U8) {
 		// fp32 queries -> uint8 (trunc); values outside [0,255] are counted and rejected below
 		const size_t nv = m * (size_t)h->dim;
-		if (nv > h->q8_bytes) {
-			if (h->d_q8) hipFree(h->d_q8);
-			h->d_q8 = nullptr;
-			h->q8_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_q8, nv));
-			h->q8_bytes = nv;
-		}
+		HIP_TRY(h, h->d_q8.ensure(nv));
 		int rcw = ensure_workspace(h, m, 2048);
 		if (rcw != EXPANN_OK)
 			return rcw;
@@ -1354,412 +1780,8 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 		if (rq != kRetryGeneric)
 			return rq;
 	}
-	bool flags_clean = false;   // the fp16 prelude has just zeroed the flag block
-	bool force_direct = false;  // set when a GEMM-form filter overflowed: massive near-ties
-	bool no_f16 = false;        // set when the queries do not fit the fp16 range of this index
-restart_direct:
-	const GemmVariant* gv = force_direct ? nullptr : pick_gemm(h, m);
-	const GemmI8Variant* gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
-	if (h->opt_scan_kernel == 2 && !gv && !gvi)
-		return h->fail(EXPANN_ERR_UNSUPPORTED,
-		               "GEMM-form scan (scan_kernel=2): f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
-	if (gvi) {
-		int rc = ensure_bias_i8(h, gvi, st);
-		if (rc != EXPANN_OK)
-			return rc;
-	}
-	const GemmBf16Variant* gvb = nullptr;
-	if (gv && h->opt_scan_kernel != 2)
-		for (const auto& v : kGemmBf16)
-			if (v.d == h->dim)
-				gvb = &v;
-	if (h->opt_scan_kernel == 3 && !gvb)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "bf16x3 GEMM-form scan: f32 L2 with dim 64 or 128 only");
-	// fp16 single-product form: default when available; a search whose queries leave the fp16
-	// range after scaling is redone with the bf16x3 form (no_f16)
-	const GemmF16Variant* gvf = nullptr;
-	if (gv && !no_f16 && f16_choice(h->opt_scan_kernel)) {
-		for (const auto& v : kGemmF16)
-			if (v.d == h->dim)
-				gvf = &v;
-		if (h->opt_scan_kernel == 6 || (h->opt_scan_kernel == 0 && h->opt_f16x))
-			for (const auto& v : ((h->opt_debug & ~16L) ? kGemmF16XDbg : kGemmF16X))
-				if (v.d == h->dim)
-					gvf = &v;
-	}
-	if ((h->opt_scan_kernel == 4 || h->opt_scan_kernel == 6) && !gvf && !no_f16)
-		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
-	if (gvf)
-		gvb = nullptr;
-	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))
-		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on / do not exist
-	if (gv && !gvf) {
-		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
-		if (rc != EXPANN_OK)
-			return rc;
-	}
-	if (gvf) {
-		int rc = ensure_f16(h, gvf, st);
-		if (rc != EXPANN_OK)
-			return rc;
-		if (h->f16_scale < 0.0f) {  // the index does not fit the fp16 range at any allowed scale
-			no_f16 = true;
-			goto restart_direct;
-		}
-		rc = ensure_workspace(h, m, cap);
-		if (rc != EXPANN_OK)
-			return rc;
-		const size_t nv = m * (size_t)h->dim;
-		if (nv * 4 > h->q_split_bytes) {
-			if (h->d_q_split) hipFree(h->d_q_split);
-			h->d_q_split = nullptr;
-			h->q_split_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_q_split, nv * 4));
-			h->q_split_bytes = nv * 4;
-		}
-		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end):
-		// one memset of the flag block, one kernel
-		// (latency mode, one workgroup: the kernel clears the flag block itself and, when the queries
-		// still sit in pinned host memory, leaves the device copy the later kernels read)
-		const bool one_wg = m <= (size_t)kRowsPerGroup;
-		const bool from_host = h->q_in_pinned_host && one_wg;
-		if (!one_wg)
-			HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, 32, st));
-		flags_clean = true;
-		hipLaunchKernelGGL(gvf->prep, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)), dim3(kBlock),
-		                   0, st, (const float*)d_queries, (uint32_t)m, h->f16_scale, (_Float16*)h->d_q_split,
-		                   h->d_qnrm, h->d_overflow + 2, from_host ? (float*)h->d_q : (float*)nullptr,
-		                   one_wg ? h->d_overflow : (uint32_t*)nullptr);
-		HIP_TRY(h, hipGetLastError());
-		if (from_host) {
-			d_queries = h->d_q;
-			h->q_in_pinned_host = false;
-		}
-	}
-	if (gvb) {  // queries -> bf16 hi/lo planes
-		const size_t nv = m * (size_t)h->dim;
-		if (nv * 4 > h->q_split_bytes) {
-			if (h->d_q_split) hipFree(h->d_q_split);
-			h->d_q_split = nullptr;
-			h->q_split_bytes = 0;
-			HIP_TRY(h, hipMalloc(&h->d_q_split, nv * 4));
-			h->q_split_bytes = nv * 4;
-		}
-		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
-		                   dim3(kBlock), 0, st, (const float*)d_queries, m, h->dim,
-		                   (__bf16*)h->d_q_split);
-		HIP_TRY(h, hipGetLastError());
-	}
-
-	for (int attempt = 0;; ++attempt) {
-		int rc = ensure_workspace(h, m, cap);
-		if (rc != EXPANN_OK)
-			return rc;
-		std::vector<Level> levels = plan_levels(h->n, k, cap, h->opt_sample_ratio);
-		const uint32_t n_qtiles = (uint32_t)((m + sv->tq - 1) / sv->tq);
-		if (!gv && !gvi && levels.size() >= 3 && h->opt_sample_pass) {
-			// direct path: ONE sampled level of class minima (1/16 of the rows) instead of the
-			// first two levels of the ladder -- a launch chain shorter by a scan, a select and a
-			// memset, and ~10 k instead of ~32 k candidates in the full scan
-			const uint32_t n_groups = (uint32_t)((h->n + kRowsPerGroup - 1) / kRowsPerGroup);
-			const uint32_t sel = n_groups / 16;
-			uint32_t blocks = std::min<uint32_t>({128u, cap / 16, sel / 8});
-			if (blocks * 16 >= 8 * k && blocks >= 16) {
-				Level l0;
-				l0.n_groups_sel = sel;
-				l0.group_stride = 16;
-				l0.classmin_blocks = blocks;
-				levels.clear();
-				levels.push_back(l0);
-				levels.push_back(Level{n_groups, 1, 0});
-			}
-		}
-		if (!flags_clean) {  // overflow count and statistics (words 1, 2: uint8 / fp16 range flags, kept)
-			HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(uint32_t), st));
-			HIP_TRY(h, hipMemsetAsync(h->d_total, 0, sizeof(unsigned long long) * 2, st));
-		}
-		flags_clean = false;
-		// fp16 form on a large index: ONE sampled pass (1/16 of the rows, class maxima per query,
-		// scan_gemm_f16.hpp) gives the threshold of the full scan -- no direct level-0 scan, no
-		// intermediate candidate lists and selects
-		size_t li_start = 0;
-		bool theta_ready = false;  // the sample pass also wrote theta' and zeroed the list counters
-		if (gvf && h->opt_sample_pass && levels.size() >= 2) {
-			const int rs = sampled_pass_f16(h, gvf, m, k, ip, cus, h->d_tau[levels.size() & 1],
-			                                h->d_tau_row[levels.size() & 1], st, &theta_ready);
-			if (rs != EXPANN_OK)
-				return rs;
-			if (theta_ready)
-				li_start = levels.size() - 1;
-		}
-		for (size_t li = li_start; li < levels.size(); ++li) {
-			const Level& L = levels[li];
-			const bool first = (li == 0), last = (li + 1 == levels.size());
-			ScanParams sp{};
-			sp.base = h->d_base;
-			sp.n_rows = (uint32_t)h->n;
-			sp.n_groups_sel = L.n_groups_sel;
-			sp.group_stride = L.group_stride;
-			sp.n_qtiles = n_qtiles;
-			sp.queries = d_queries;
-			sp.m = (uint32_t)m;
-			sp.tau = first ? nullptr : h->d_tau[(li + 1) & 1];
-			sp.tau_row = first ? nullptr : h->d_tau_row[(li + 1) & 1];
-			sp.cand_cnt = h->d_cnt;
-			sp.cand = h->d_cand;
-			sp.cap = cap;
-			// ~16 workgroups per CU in total, at least 8 groups (128 rows) per workgroup
-			uint32_t target_chunks = (uint32_t)std::max<long>(1, (16L * cus + n_qtiles - 1) / n_qtiles);
-			uint32_t max_chunks = std::max<uint32_t>(1, L.n_groups_sel / 8);
-			uint32_t n_chunks = std::min(target_chunks, max_chunks);
-			if (first && L.classmin_blocks) {
-				n_chunks = L.classmin_blocks;
-				sp.classmin = 1;
-			}
-			sp.groups_per_block = (L.n_groups_sel + n_chunks - 1) / n_chunks;
-			n_chunks = (L.n_groups_sel + sp.groups_per_block - 1) / sp.groups_per_block;
-			if (!first && !theta_ready)
-				HIP_TRY(h, hipMemsetAsync(h->d_cnt, 0, sizeof(uint32_t) * m, st));
-			const bool use_gemm = gv && !first;
-			const bool timed = last && h->profiling && h->ev_used < kEventPairs;
-			uint32_t passes = n_qtiles;
-			const char* kname = sv->name;
-			uint32_t qt_used = (uint32_t)sv->tq;
-			if (use_gemm) {
-				// theta_q = tau_q - ||q||^2 (1-eps), then the MFMA filter over 128-row tiles
-				const float f16_abs = gvf ? std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
-				                          : 0.0f;
-				if (gvf && theta_ready)
-					;
-				else if (gvf)
-					hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
-					                   dim3(kBlock), 0, st, (const float*)h->d_qnrm, (uint32_t)m,
-					                   gemm_f16_filter_eps(h->dim), f16_abs, (const float*)sp.tau,
-					                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0);
-				else
-					hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
-					                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
-					                   (const float*)sp.tau,
-					                   1.0f - (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)),
-					                   h->d_theta);
-				GemmScanParams gp{};
-				gp.base = (const float*)h->d_base;
-				gp.bnorm = h->d_bnorm;
-				gp.n_rows = (uint32_t)h->n;
-				const uint32_t n_tiles = (uint32_t)((h->n + kGemmTB - 1) / kGemmTB);
-				gp.n_tiles_sel = last ? n_tiles
-				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + kGemmTB - 1) / kGemmTB);
-				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				const uint32_t tq_wg = gvf ? (uint32_t)gvf->wgq : (gvb ? kGemmBf16TQ : kGemmTQ);
-				uint32_t tq_small = 0;
-				gp.n_qtiles = (uint32_t)((m + tq_wg - 1) / tq_wg);
-				gp.queries = (const float*)d_queries;
-				gp.theta = h->d_theta;
-				gp.m = (uint32_t)m;
-				gp.cand_cnt = h->d_cnt;
-				gp.cand = h->d_cand;
-				gp.cap = cap;
-				// One workgroup per CU is resident (128 KiB of LDS), so the launch runs in rounds
-				// of `cus` workgroups: pick the row-chunk count that minimises
-				// rounds x (steps per workgroup + ~2 steps of prologue).
-				uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 1024, 0, nullptr);
-				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
-				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
-				if (timed)
-					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				if (gvf) {
-					const int rl = launch_scan_f16(h, gvf, L.n_groups_sel * kRowsPerGroup, last, m, cus, ip, cap, st, &kname,
-					                               &gp.n_qtiles, &tq_small);
-					if (rl != EXPANN_OK)
-						return rl;
-				} else if (gvb) {
-					GemmBf16Params bp{};
-					bp.base_split = h->d_base_split;
-					bp.bnorm = h->d_bnorm_bf;
-					bp.n_rows = gp.n_rows;
-					bp.n_tiles_sel = gp.n_tiles_sel;
-					bp.tile_stride = gp.tile_stride;
-					bp.tile_run = 1;
-					if (!last && gp.tile_stride >= 8) {
-						// sampled level: runs of 8 consecutive tiles (one 2 MiB page each at d=128)
-						// instead of isolated tiles, same number of tiles
-						bp.tile_run = 8;
-						bp.n_tiles_sel = (gp.n_tiles_sel / 8) * 8;
-						if (bp.n_tiles_sel == 0) {
-							bp.n_tiles_sel = gp.n_tiles_sel;
-							bp.tile_run = 1;
-						}
-					}
-					bp.tiles_per_block = gp.tiles_per_block;
-					bp.n_qtiles = gp.n_qtiles;
-					bp.queries_split = h->d_q_split;
-					bp.theta = gp.theta;
-					bp.m = gp.m;
-					bp.cand_cnt = gp.cand_cnt;
-					bp.cand = gp.cand;
-					bp.cap = gp.cap;
-					bp.debug = (uint32_t)h->opt_debug;
-					hipLaunchKernelGGL(gvb->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-					                   2 * kGemmTB * h->dim * sizeof(float), st, bp);
-					kname = gvb->name;
-				} else {
-					hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-					                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
-					kname = gv->name;
-				}
-				passes = gp.n_qtiles;
-				qt_used = tq_small ? tq_small : tq_wg;  // (launch_scan_f16 reports the tile it used)
-			} else if (gvi && !first) {
-				hipLaunchKernelGGL(gvi->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
-				                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)sp.tau,
-				                   (int*)h->d_theta, h->d_qself);
-				const uint32_t tb = (uint32_t)gemm_i8_tb(h->dim);
-				GemmI8Params gp{};
-				gp.base = h->d_base;
-				gp.bias = h->d_bias_i;
-				gp.n_rows = (uint32_t)h->n;
-				const uint32_t n_tiles = (uint32_t)((h->n + tb - 1) / tb);
-				gp.n_tiles_sel = last ? n_tiles
-				                      : std::min(n_tiles, (L.n_groups_sel * kRowsPerGroup + tb - 1) / tb);
-				gp.tile_stride = std::max<uint32_t>(1, n_tiles / gp.n_tiles_sel);
-				gp.n_qtiles = (uint32_t)((m + kGemmI8TQ - 1) / kGemmI8TQ);
-				gp.queries = d_queries;
-				gp.theta = (const int*)h->d_theta;
-				gp.qself = h->d_qself;
-				gp.m = (uint32_t)m;
-				gp.cand_cnt = h->d_cnt;
-				gp.cand = h->d_cand;
-				gp.cap = cap;
-				uint32_t gchunks = pick_row_chunks(gp.n_tiles_sel, gp.n_qtiles, (uint32_t)cus, 2.0, 4, 4096, 0, nullptr);
-				gp.tiles_per_block = (gp.n_tiles_sel + gchunks - 1) / gchunks;
-				gchunks = (gp.n_tiles_sel + gp.tiles_per_block - 1) / gp.tiles_per_block;
-				if (timed)
-					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				hipLaunchKernelGGL(gvi->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-				                   2 * tb * h->dim, st, gp);
-				passes = gp.n_qtiles;
-				kname = gvi->name;
-				qt_used = kGemmI8TQ;
-			} else {
-				if (timed)
-					HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-				hipLaunchKernelGGL(sv->fn, dim3(n_chunks * n_qtiles), dim3(kBlock), 0, st, sp);
-			}
-			if (timed) {
-				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
-				h->ev_used++;
-			}
-			if (h->pending_scatter.n_logs) {  // scan_gemm_f16x: file the per-wave hit logs into the lists
-				const auto ps = h->pending_scatter;
-				h->pending_scatter.n_logs = 0;
-				// ~1024 workgroups: the logs of a (query tile, wave) pair are split over n_groups of them
-				const uint32_t want = std::max<uint32_t>(1, (1024 + ps.n_qtiles * 4 - 1) / (ps.n_qtiles * 4));
-				const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
-				const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
-				GatherLogParams gp{(const uint4*)h->d_log, (const uint32_t*)h->d_log_cnt, ps.log_cap, ps.n_chunks,
-				                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
-				hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
-			}
-			if (last && (timed || !h->profiling)) {
-				h->prof.scan_launches++;
-				h->prof.scan_rows += h->n;
-				h->prof.scan_query_tiles += passes;
-				h->prof.query_tile = qt_used;
-				h->prof.levels = (uint32_t)(levels.size() - li_start + (li_start ? 1 : 0));
-				std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", kname);
-			}
-			HIP_TRY(h, hipGetLastError());
-
-			SelectParams sel{};
-			sel.cand = h->d_cand;
-			sel.cand_cnt = first ? nullptr : h->d_cnt;
-			sel.fixed_count = (first && L.classmin_blocks) ? n_chunks * 16 : L.n_groups_sel * kRowsPerGroup;
-			sel.cap = cap;
-			sel.k = (uint32_t)k;
-			sel.id_offset = h->id_offset;
-			sel.out_ids = last ? d_ids : nullptr;
-			sel.out_dists = last ? d_dists : nullptr;
-			sel.tau_out = last ? nullptr : h->d_tau[li & 1];
-			sel.tau_prev = first ? nullptr : h->d_tau[(li + 1) & 1];
-			sel.tau_row_out = last ? nullptr : h->d_tau_row[li & 1];
-			sel.tau_row_prev = first ? nullptr : h->d_tau_row[(li + 1) & 1];
-			sel.rerank_base = use_gemm ? (const float*)h->d_base : nullptr;
-			sel.rerank_queries = use_gemm ? (const float*)d_queries : nullptr;
-			sel.dim = (uint32_t)h->dim;
-			sel.metric_ip = ip ? 1u : 0u;
-			// (inner product, fp16 form only: the approximate key is off by at most E_q + E_b in
-			// total, half the L2 margins)
-			const float pr = ip ? 1.0f : 2.0f;
-			sel.prune_eps = use_gemm ? (gvf ? pr * gemm_f16_filter_eps(h->dim)
-			                                : (gvb ? gemm_bf16_filter_eps(h->dim) : gemm_filter_eps(h->dim)))
-			                         : 0.0f;
-			sel.prune_abs = (use_gemm && gvf)
-			                    ? pr * std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim)
-			                    : 0.0f;
-			sel.bn_max = h->d_bnmax ? h->d_bnmax + (gvf ? 2 : (gvb ? 1 : 0)) : nullptr;
-			sel.qnrm = (use_gemm && gvf) ? h->d_qnrm : nullptr;
-			sel.overflow = h->d_overflow;
-			if (last && sel.cand_cnt && h->profiling)  // statistics: candidates of the full scan
-				hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
-				                   h->d_total);
-			if (m <= 64) {
-				sel.wave0_short = 1;  // latency mode: one launch, wave 0 orders the short lists
-			} else if (sel.rerank_base && sel.cand_cnt) {
-				// short lists (the usual case after a GEMM-form scan): one wave per query
-				launch_select_wave(sel, m, cap, st);
-			}
-			hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
-			                   sizeof(uint64_t) * cap + 16, st, sel);
-			HIP_TRY(h, hipGetLastError());
-		}
-		// overflow check (the only host sync of a search); flags and statistics are contiguous
-		if (defer_flags(h, st, attempt)) {  // deferred check: expann_sync reads the flags
-			float sc = gvf ? h->f16_scale : 0.0f;  // (fp16 form: the range check of max |q| needs the scale)
-			std::memcpy(&h->h_flag_ring[8 * (h->async_pending - 1) + 6], &sc, sizeof(float));
-			return EXPANN_OK;
-		}
-		HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long),
-		                          hipMemcpyDeviceToHost, st));
-		HIP_TRY(h, hipStreamSynchronize(st));
-		unsigned long long tot;
-		std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
-		h->prof.candidates = tot;
-		if (gvf) {  // queries outside the fp16 range of this index: redo with the bf16x3 form
-			float qmax;  // bit pattern of max |q| (flags word 2, read back with the overflow flags)
-			std::memcpy(&qmax, &h->h_flags[2], sizeof(float));
-			if (!(qmax * h->f16_scale <= 60000.0f)) {
-				no_f16 = true;
-				h->prof.retries++;
-				goto restart_direct;
-			}
-		}
-		if (h->strict_u8 && (h->h_flags[1] != 0 || h->h_flags[3] != 0))
-			return kStrictReject;
-		if (h->dtype == EXPANN_DTYPE_U8 && h->h_flags[1] != 0)
-			return h->fail(EXPANN_ERR_UNSUPPORTED,
-			               std::to_string(h->h_flags[1]) +
-			                   " query values outside [0,255]: the uint8 metric "
-			                   "(dist2_compressed) is only defined for 8-bit valued queries");
-		if (h->h_flags[0] == 0)
-			return EXPANN_OK;
-		// some candidate list overflowed: retry with 4x the capacity
-		h->prof.retries++;
-		if (gvf && gvf->hit_log)  // (or a hit log / queue of the 16x16x32 form: the direct appends have no such limit)
-			for (const auto& v : kGemmF16)
-				if (v.d == h->dim)
-					gvf = &v;
-		if ((cap >= kMaxCap || attempt >= 3) && (gv || gvi) && h->opt_scan_kernel == 0) {
-			// the GEMM forms cannot break exact ties by row number; the direct scan can
-			force_direct = true;
-			goto restart_direct;
-		}
-		if (cap >= kMaxCap || attempt >= 3)
-			return h->fail(EXPANN_ERR_OVERFLOW,
-			               "candidate lists overflowed (" + std::to_string(h->h_flags[0]) +
-			                   " queries) at capacity " + std::to_string(cap) +
-			                   "; the data has more near-ties than the threshold filter supports");
-		cap = std::min(cap * 4, kMaxCap);
-	}
+	SearchPass pass{h, d_queries, m, k, d_ids, d_dists, st, ip, cus, cap, svs};
+	return pass.run();
 }
 
 }  // namespace
@@ -1931,38 +1953,8 @@ void expann_destroy(expann_index* h) {
 	if (h->stream) hipStreamSynchronize(h->stream);
 	drop_u8_shadow(h);
 	if (h->owns_base && h->d_base) hipFree(h->d_base);
-	if (h->d_cand) hipFree(h->d_cand);
-	if (h->d_cnt) hipFree(h->d_cnt);
-	if (h->d_tau[0]) hipFree(h->d_tau[0]);
-	if (h->d_tau[1]) hipFree(h->d_tau[1]);
-	if (h->d_tau_row[0]) hipFree(h->d_tau_row[0]);
-	if (h->d_tau_row[1]) hipFree(h->d_tau_row[1]);
-	if (h->d_overflow) hipFree(h->d_overflow);
-	if (h->d_bnorm) hipFree(h->d_bnorm);
-	if (h->d_bnorm_bf) hipFree(h->d_bnorm_bf);
-	if (h->d_bnmax) hipFree(h->d_bnmax);
-	if (h->d_base_f16) hipFree(h->d_base_f16);
-	if (h->d_bnorm_f16) hipFree(h->d_bnorm_f16);
-	if (h->d_bns_f16) hipFree(h->d_bns_f16);
-	if (h->d_qnrm) hipFree(h->d_qnrm);
-	if (h->d_sample) hipFree(h->d_sample);
-	if (h->d_log) hipFree(h->d_log);
-	if (h->d_log_cnt) hipFree(h->d_log_cnt);
 	if (h->d_base_i8q && h->base_i8q_owned) hipFree(h->d_base_i8q);
-	if (h->d_bp_i8q) hipFree(h->d_bp_i8q);
-	if (h->d_base_split) hipFree(h->d_base_split);
-	if (h->d_q_split) hipFree(h->d_q_split);
-	if (h->d_bias_i) hipFree(h->d_bias_i);
-	if (h->d_qself) hipFree(h->d_qself);
-	if (h->d_theta) hipFree(h->d_theta);
-	if (h->h_flags) hipHostFree(h->h_flags);
-	if (h->h_flag_ring) hipHostFree(h->h_flag_ring);
-	if (h->h_pin) hipHostFree(h->h_pin);
-	if (h->d_ticket) hipFree(h->d_ticket);
-	if (h->d_q) hipFree(h->d_q);
-	if (h->d_q8) hipFree(h->d_q8);
-	if (h->d_ids) hipFree(h->d_ids);
-	if (h->d_dists) hipFree(h->d_dists);
+	// (every other buffer is a DevPtr / PinPtr member: freed by `delete h` below, device still current)
 	if (h->ev_created)
 		for (int i = 0; i < kEventPairs; ++i) {
 			hipEventDestroy(h->ev[i][0]);
@@ -2027,42 +2019,19 @@ int expann_set_base_device(expann_index* h, const void* d_rows, size_t n, uint64
 	if (h->owns_base && h->d_base)
 		hipFree(h->d_base);
 	drop_u8_shadow(h);
-	if (h->d_bnorm) {
-		hipFree(h->d_bnorm);
-		h->d_bnorm = nullptr;
-	}
-	if (h->d_bias_i) {
-		hipFree(h->d_bias_i);
-		h->d_bias_i = nullptr;
-	}
-	if (h->d_bnorm_bf) {
-		hipFree(h->d_bnorm_bf);
-		h->d_bnorm_bf = nullptr;
-	}
-	if (h->d_base_split) {
-		hipFree(h->d_base_split);
-		h->d_base_split = nullptr;
-	}
-	if (h->d_base_f16) {
-		hipFree(h->d_base_f16);
-		h->d_base_f16 = nullptr;
-	}
+	// the derived copies belong to the rows they were made from
+	h->d_bnorm.reset();
+	h->d_bias_i.reset();
+	h->d_bnorm_bf.reset();
+	h->d_base_split.reset();
+	h->d_base_f16.reset();
 	if (h->d_base_i8q && h->base_i8q_owned)
 		hipFree(h->d_base_i8q);
 	h->d_base_i8q = nullptr;
 	h->base_i8q_owned = false;
-	if (h->d_bp_i8q) {
-		hipFree(h->d_bp_i8q);
-		h->d_bp_i8q = nullptr;
-	}
-	if (h->d_bnorm_f16) {
-		hipFree(h->d_bnorm_f16);
-		h->d_bnorm_f16 = nullptr;
-	}
-	if (h->d_bns_f16) {
-		hipFree(h->d_bns_f16);
-		h->d_bns_f16 = nullptr;
-	}
+	h->d_bp_i8q.reset();
+	h->d_bnorm_f16.reset();
+	h->d_bns_f16.reset();
 	h->f16_scale = 0.0f;
 	h->d_base = const_cast<void*>(d_rows);
 	h->owns_base = false;
@@ -2153,26 +2122,19 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 	}
 	HIP_TRY(h, hipSetDevice(h->device));
 	const size_t qbytes = m * (size_t)h->dim * h->q_elem;
-	if (qbytes > h->io_q_bytes) {
-		if (h->d_q) hipFree(h->d_q);
-		h->d_q = nullptr;
-		h->io_q_bytes = 0;
-		HIP_TRY(h, hipMalloc(&h->d_q, qbytes));
-		h->io_q_bytes = qbytes;
-	}
+	HIP_TRY(h, h->d_q.ensure(qbytes));
 	if (m * k <= 16384 && qbytes <= (256u << 10) && m <= kMaxQueriesPerPass && h->opt_latency_mode) {
 		const size_t ids_off = (qbytes + 63) / 64 * 64;
 		const size_t dists_off = ids_off + sizeof(uint64_t) * m * k;
 		const size_t need = dists_off + sizeof(float) * m * k;
 		if (need > h->h_pin_bytes) {
-			if (h->h_pin) hipHostFree(h->h_pin);
-			h->h_pin = nullptr;
+			h->h_pin.reset();
 			h->h_pin_bytes = 0;
 			const size_t want = std::max<size_t>(need, 64u << 10);
 			HIP_TRY(h, hipHostMalloc(&h->h_pin, want, hipHostMallocDefault));
 			h->h_pin_bytes = want;
 		}
-		char* pin = (char*)h->h_pin;
+		char* pin = h->h_pin.as<char>();
 		std::memcpy(pin, queries, qbytes);
 		// fp32 index with its fp16 copy in place and at most one workgroup of queries: the query
 		// prep kernel reads them straight from pinned memory (and makes the device copy); otherwise
@@ -2200,16 +2162,8 @@ int expann_search(expann_index* h, const void* queries, size_t m, size_t k, uint
 			std::memcpy(dists, pin + dists_off, sizeof(float) * m * k);
 		return EXPANN_OK;
 	}
-	if (m * k > h->io_out) {
-		if (h->d_ids) hipFree(h->d_ids);
-		if (h->d_dists) hipFree(h->d_dists);
-		h->d_ids = nullptr;
-		h->d_dists = nullptr;
-		h->io_out = 0;
-		HIP_TRY(h, hipMalloc(&h->d_ids, sizeof(uint64_t) * m * k));
-		HIP_TRY(h, hipMalloc(&h->d_dists, sizeof(float) * m * k));
-		h->io_out = m * k;
-	}
+	HIP_TRY(h, h->d_ids.ensure(sizeof(uint64_t) * m * k));
+	HIP_TRY(h, h->d_dists.ensure(sizeof(float) * m * k));
 	HIP_TRY(h, hipMemcpyAsync(h->d_q, queries, qbytes, hipMemcpyHostToDevice, h->stream));
 	h->host_call = true;
 	int rc = expann_search_device(h, h->d_q, m, k, h->d_ids, h->d_dists, h->stream);
