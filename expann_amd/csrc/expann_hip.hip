@@ -409,7 +409,9 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 #define F16X_V(D)                                                                                  \
 	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,           \
 	 f16_query_prep_kernel<D>, "scan_gemm_f16x<" #D ", false>", kF16TB, kF16TQ, kF16Threads, 2,      \
-	 gemm_f16_lds_bytes<128>(), 1}
+	 gemm_f16x_lds_bytes<D>(), 1}
+// (d = 64 measured slower on this form than on scan_gemm_f16_kernel<64>'s three workgroups per CU:
+// 6.55 M vs 6.83 M QPS at 1 M rows -- two k-steps per column leave too little MFMA per step)
 const GemmF16Variant kGemmF16X[] = {F16X_V(128)};
 #undef F16X_V
 // the same with the run-time ablation switches compiled in ("debug" option != 0)
@@ -1300,9 +1302,14 @@ int SearchPass::choose_kernels() {
 			if (v.d == h->dim)
 				gvf = &v;
 		if (h->opt_scan_kernel == 6 || (h->opt_scan_kernel == 0 && h->opt_f16x))
-			for (const auto& v : ((h->opt_debug & ~16L) ? kGemmF16XDbg : kGemmF16X))
-				if (v.d == h->dim)
-					gvf = &v;
+			{
+				const bool dbg = (h->opt_debug & ~16L) != 0;  // (the debug instance exists for d = 128 only)
+				for (const auto& v : kGemmF16X)
+					if (v.d == h->dim && !(dbg && v.d == kGemmF16XDbg[0].d))
+						gvf = &v;
+				if (dbg && kGemmF16XDbg[0].d == h->dim)
+					gvf = &kGemmF16XDbg[0];
+			}
 	}
 	if ((h->opt_scan_kernel == 4 || h->opt_scan_kernel == 6) && !gvf && !no_f16)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
@@ -1895,7 +1902,15 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 				delete h;
 				return EXPANN_ERR_HIP;
 			}
-	for (const auto* tab : {kGemmF16X, kGemmF16XDbg})
+	for (const auto& v : kGemmF16X)
+		if (v.d == dim &&
+		    hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess) {
+			g_create_error = "hipFuncSetAttribute(scan_gemm_f16x_kernel) failed";
+			hipStreamDestroy(h->stream);
+			delete h;
+			return EXPANN_ERR_HIP;
+		}
+	for (const auto* tab : {kGemmF16XDbg})
 		if (tab[0].d == dim)
 			if (hipFuncSetAttribute((const void*)tab[0].scan, hipFuncAttributeMaxDynamicSharedMemorySize, tab[0].lds) !=
 			    hipSuccess) {

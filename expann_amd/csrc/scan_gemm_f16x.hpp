@@ -27,6 +27,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // DBG = 1 compiles the run-time ablation switches of p.debug in (bench only: 1 no barrier, 2 no
 // staging, 4 no epilogue, 8 no candidate path, 32 no LDS fragment reads, 64 flushes drop their hits);
 // the production instance has none of their branches, so a step's MFMA stream is ONE basic block.
+// LDS of one workgroup: tiles + per-wave bn' slots + per-wave queues + theta' + queue fills
+template <int D> constexpr int gemm_f16x_lds_bytes() {
+	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 16;
+}
+static_assert(gemm_f16x_lds_bytes<128>() == gemm_f16_lds_bytes<128>(), "same LDS map as scan_gemm_f16_kernel<128>");
+
 template <int D, bool SAMPLE, int DBG = 0>
 __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16x_kernel(GemmF16Params p) {
 	const uint32_t dbg = DBG ? p.debug : 0u;
