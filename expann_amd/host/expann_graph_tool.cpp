@@ -93,6 +93,18 @@ int main(int argc, char** argv) {
 			std::ofstream qf(a["queries"], std::ios::binary);
 			qf.write(reinterpret_cast<const char*>(queries.data()), (std::streamsize)(queries.size() * 4));
 		}
+		if (get("strided-roundtrip", "0") == "1") {
+			// the batched builder's view of the graph (fixed-stride rows) and back: must be lossless
+			auto g = eng.index.to_strided({}, 64);
+			expann::antitopo_index copy(eng.index.dim, eng.index.conf);
+			copy.hadj_flat_with_lengths.clear();
+			const std::vector<float> rows = eng.index.vectors;
+			copy.from_strided(g, rows.data(), eng.index.max_layer, eng.index.starting_vertex);
+			copy.has_ef_search = eng.index.has_ef_search;
+			copy.ef_search = eng.index.ef_search;
+			eng.index.hadj_flat_with_lengths = copy.hadj_flat_with_lengths;
+			eng.index.hadj_flat = copy.hadj_flat;
+		}
 		if (a.count("rewrite")) {  // read_index -> write_index round trip
 			eng.index.write_index(a["rewrite"]);
 		}

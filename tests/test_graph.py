@@ -45,6 +45,17 @@ def test_builder_index_format_roundtrip_and_graph_quality(tmp_path, oracle):
     assert recalls[0] < recalls[1] <= recalls[2] and recalls[2] > 0.99
 
 
+def test_strided_view_of_the_graph_is_lossless(tmp_path):
+    """antitopo_index::to_strided / from_strided (the fixed-stride adjacency arrays the batched GPU
+    builder works on) reproduce the index byte for byte -- CPU only."""
+    idx, idx2 = tmp_path / "g.index", tmp_path / "g2.index"
+    _tool("--n", 600, "--m", 1, "--d", 64, "--M", 8, "--ef_construction", 40, "--data", "gauss",
+          "--build-only", 1, "--index", idx)
+    _tool("--n", 0, "--m", 1, "--d", 64, "--build-only", 1, "--read-index", 1, "--index", idx,
+          "--strided-roundtrip", 1, "--rewrite", idx2)
+    assert open(idx, "rb").read() == open(idx2, "rb").read()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("data,d", [("sift", 128), ("gauss", 64), ("sift", 960), ("sift", 832)])
 def test_gpu_traversal_matches_oracle(tmp_path, oracle, data, d):
