@@ -27,6 +27,7 @@
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_gemm_i8q.hpp"
+#include "scan_gemm_i8x.hpp"
 #include "scan_int8.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
@@ -136,6 +137,7 @@ struct expann_index {
 	                                 // full scan drowned in candidates (90 k instead of 2.8 M QPS on
 	                                 // 1000 contiguous clusters); on iid rows the two differ by < 1 %
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
+	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
 	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
@@ -708,6 +710,18 @@ const GemmI8qVariant kGemmI8q[] = {
     GEMM_I8Q_P(832, 1024, kI8IP, false, "I8IP"),
     GEMM_I8Q_P(960, 1024, kU8L2, true, "U8L2"), GEMM_I8Q_P(960, 1024, kI8L2, true, "I8L2"),
     GEMM_I8Q_P(960, 1024, kI8IP, false, "I8IP")};
+// the 16x16x64 form of the full scan for the 8-waves-per-tile geometries (scan_gemm_i8x.hpp); the
+// sampled pass stays scan_gemm_i8q_kernel<DQ, L2F, true>
+#define GEMM_I8X_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8x_kernel<DQ, L2F>, \
+	scan_gemm_i8q_kernel<DQ, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+	"scan_gemm_i8x<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
+const GemmI8qVariant kGemmI8x[] = {
+    GEMM_I8X_P(768, 768, kU8L2, true, "U8L2"), GEMM_I8X_P(768, 768, kI8L2, true, "I8L2"), GEMM_I8X_P(768, 768, kI8IP, false, "I8IP"),
+    GEMM_I8X_P(832, 1024, kU8L2, true, "U8L2"), GEMM_I8X_P(832, 1024, kI8L2, true, "I8L2"),
+    GEMM_I8X_P(832, 1024, kI8IP, false, "I8IP"),
+    GEMM_I8X_P(960, 1024, kU8L2, true, "U8L2"), GEMM_I8X_P(960, 1024, kI8L2, true, "I8L2"),
+    GEMM_I8X_P(960, 1024, kI8IP, false, "I8IP")};
+#undef GEMM_I8X_P
 #undef GEMM_I8Q
 #undef GEMM_I8Q_P
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
@@ -720,6 +734,10 @@ const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
 		return nullptr;
 	if (h->n < 2 * 256 * kF16TB || k > 256)
 		return nullptr;
+	if (h->opt_i8x)
+		for (const auto& v : kGemmI8x)
+			if (v.d == h->dim && v.mode == h->int_mode)
+				return &v;
 	for (const auto& v : kGemmI8q)
 		if (v.d == h->dim && v.mode == h->int_mode)
 			return &v;
@@ -1875,8 +1893,10 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : (dtype == EXPANN_DTYPE_I16 ? 2 : 1);
 	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : (dtype == EXPANN_DTYPE_I16 ? 2 : 4);
 	h->int_mode = int_mode;
-	if (const char* e = std::getenv("EXPANN_F16X"))  // A/B switch of the fp16 scan's MFMA shape (tests, bench)
+	if (const char* e = std::getenv("EXPANN_F16X"))  // A/B switches of the scans' MFMA shape (tests, bench)
 		h->opt_f16x = std::atol(e);
+	if (const char* e = std::getenv("EXPANN_I8X"))
+		h->opt_i8x = std::atol(e);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -1919,6 +1939,14 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 				delete h;
 				return EXPANN_ERR_HIP;
 			}
+	for (const auto& v : kGemmI8x)
+		if (v.d == dim &&
+		    hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess) {
+			g_create_error = "hipFuncSetAttribute(scan_gemm_i8x_kernel) failed";
+			hipStreamDestroy(h->stream);
+			delete h;
+			return EXPANN_ERR_HIP;
+		}
 	for (const auto& v : kGemmI8q)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2358,6 +2386,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_scan_kernel = value;
 	else if (!std::strcmp(name, "f16x"))
 		h->opt_f16x = value;
+	else if (!std::strcmp(name, "i8x"))
+		h->opt_i8x = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

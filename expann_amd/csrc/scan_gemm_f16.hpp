@@ -333,7 +333,7 @@ static_assert(F16Geom<128>::WGQ == kF16TQ && F16Geom<256>::WGQ == kF16TQ, "one q
 template <int D> constexpr int gemm_f16_lds_bytes() {
 	using G = F16Geom<D>;
 	// tiles + per-wave bn' slots + per-wave candidate queues + theta' + queue fills
-	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16 +
+	return G::NBUF * (kF16TB * D * 2 + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 64 +
 	       (G::TH_LDS ? G::WAVES * 2 * G::TQW * 16 * 4 : 0);
 }
 static_assert(gemm_f16_lds_bytes<64>() * 3 <= 160 * 1024 &&
@@ -395,7 +395,7 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
 	constexpr bool THL = G::TH_LDS && !SAMPLE;
 	// (THL) accumulator start values by (wave, lane half): 16 per query tile, read back as broadcasts
-	float* const thl = reinterpret_cast<float*>(fills + 4) + (wave * 2 + h) * (TQW * 16);
+	float* const thl = reinterpret_cast<float*>(fills + 16) + (wave * 2 + h) * (TQW * 16);
 
 	f16x8 a[TQW][KS];
 #pragma unroll

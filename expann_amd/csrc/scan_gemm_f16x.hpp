@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the production instance has none of their branches, so a step's MFMA stream is ONE basic block.
 // LDS of one workgroup: tiles + per-wave bn' slots + per-wave queues + theta' + queue fills
 template <int D> constexpr int gemm_f16x_lds_bytes() {
-	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 16;
+	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 64;
 }
 static_assert(gemm_f16x_lds_bytes<128>() == gemm_f16_lds_bytes<128>(), "same LDS map as scan_gemm_f16_kernel<128>");
 

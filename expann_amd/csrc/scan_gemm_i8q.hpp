@@ -104,7 +104,8 @@ static_assert(I8qGeom<128>::WGQ == kF16TQ && I8qGeom<768>::WGQ == kF16TQ, "one q
 
 template <int D> constexpr int gemm_i8q_lds_bytes() {
 	using G = I8qGeom<D>;
-	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 16 +
+	// tiles + per-wave bp slots + per-wave queues + accumulator start values + one fill word per wave
+	return G::NBUF * (kF16TB * D + G::WAVES * 256) + G::WAVES * G::QCAP * kF16EntryBytes + G::WGQ * 4 + 64 +
 	       (G::TH_LDS ? G::WAVES * 2 * G::TQW * 16 * 4 : 0);
 }
 static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<1024>() <= 160 * 1024 &&
@@ -164,7 +165,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
 	constexpr bool THL = G::TH_LDS && !SAMPLE;
 	// (THL) accumulator start values by (wave, lane half): 16 per query tile, read back as broadcasts
-	int* const thl = reinterpret_cast<int*>(fills + 4) + (wave * 2 + h) * (TQW * 16);
+	int* const thl = reinterpret_cast<int*>(fills + 16) + (wave * 2 + h) * (TQW * 16);
 
 	constexpr int kNever = -2147483647 - 1;
 	// query fragments; lane half h of k-step s holds chunk 2s + h (natural) or h*KS + s

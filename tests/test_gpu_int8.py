@@ -162,7 +162,8 @@ def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
     eng.set_option("scan_kernel", 5)
     eng.set_profiling(True)
     _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
-    assert eng.get_profile()["scan_kernel"].startswith("scan_gemm_i8q"), eng.get_profile()["scan_kernel"]
+    # (d >= 768: the 16x16x64 form scan_gemm_i8x of the same geometry, scan_gemm_i8x.hpp)
+    assert eng.get_profile()["scan_kernel"].startswith(("scan_gemm_i8q", "scan_gemm_i8x")), eng.get_profile()["scan_kernel"]
     eng.close()
 
 
