@@ -23,6 +23,7 @@
 #include "scan_gemm_f16.hpp"
 #include "scan_gemm_f16k.hpp"
 #include "scan_gemm_f16x.hpp"
+#include "scan_gemm_f16y.hpp"
 #include "scan_direct_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
@@ -414,7 +415,13 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 	 gemm_f16x_lds_bytes<D>(), 1}
 // (d = 64 measured slower on this form than on scan_gemm_f16_kernel<64>'s three workgroups per CU:
 // 6.55 M vs 6.83 M QPS at 1 M rows -- two k-steps per column leave too little MFMA per step)
-const GemmF16Variant kGemmF16X[] = {F16X_V(128)};
+// d = 256 / 512: the 8-waves-per-tile geometry on 16x16x32 (scan_gemm_f16y.hpp), hits appended directly
+#define F16Y_V(D)                                                                                  \
+	{D, scan_gemm_f16y_kernel<D>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
+	 "scan_gemm_f16y<" #D ", false>", kF16TB, F16Geom<D>::WGQ, F16Geom<D>::THREADS, F16Geom<D>::WG_PER_CU, \
+	 gemm_f16_lds_bytes<D>(), 0}
+const GemmF16Variant kGemmF16X[] = {F16X_V(128), F16Y_V(256), F16Y_V(512)};
+#undef F16Y_V
 #undef F16X_V
 // the same with the run-time ablation switches compiled in ("debug" option != 0)
 const GemmF16Variant kGemmF16XDbg[] = {{128, scan_gemm_f16x_kernel<128, false, 1>, scan_gemm_f16_kernel<128, true>,
