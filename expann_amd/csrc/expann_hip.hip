@@ -24,6 +24,7 @@
 #include "scan_gemm_f16k.hpp"
 #include "scan_gemm_f16x.hpp"
 #include "scan_gemm_f16y.hpp"
+#include "scan_gemm_f16kx.hpp"
 #include "scan_direct_f16.hpp"
 #include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
@@ -420,7 +421,13 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 	{D, scan_gemm_f16y_kernel<D>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
 	 "scan_gemm_f16y<" #D ", false>", kF16TB, F16Geom<D>::WGQ, F16Geom<D>::THREADS, F16Geom<D>::WG_PER_CU, \
 	 gemm_f16_lds_bytes<D>(), 0}
-const GemmF16Variant kGemmF16X[] = {F16X_V(128), F16Y_V(256), F16Y_V(512)};
+// 512 < d <= 960: the k-split geometry on 16x16x32 (scan_gemm_f16kx.hpp)
+#define F16KX_V(D)                                                                                 \
+	{D, scan_gemm_f16kx_kernel<D>, scan_gemm_f16k_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
+	 "scan_gemm_f16kx<" #D ", false>", F16kGeom<D>::TB, F16kGeom<D>::WGQ, F16kGeom<D>::THREADS, 1,     \
+	 F16kGeom<D>::LDS_BYTES, 0}
+const GemmF16Variant kGemmF16X[] = {F16X_V(128), F16Y_V(256), F16Y_V(512), F16KX_V(768), F16KX_V(832), F16KX_V(960)};
+#undef F16KX_V
 #undef F16Y_V
 #undef F16X_V
 // the same with the run-time ablation switches compiled in ("debug" option != 0)
