@@ -333,8 +333,15 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 	} F;
 	Fail* fh = &F;
 	HIP_TRY(fh, hipSetDevice(device));
-	hipStream_t st = nullptr;
-	HIP_TRY(fh, hipStreamCreate(&st));
+	struct StreamGuard {  // (every early return below leaves through this)
+		hipStream_t s = nullptr;
+		~StreamGuard() {
+			if (s)
+				(void)hipStreamDestroy(s);
+		}
+	} sg;
+	HIP_TRY(fh, hipStreamCreate(&sg.s));
+	hipStream_t st = sg.s;
 	DevBuf b_vec, b_lvl, b_up, b_id0, b_d0, b_deg0, b_idu, b_du, b_degu, b_vis, b_ep, b_out, b_outc, b_tasks, b_upslot,
 	    b_dirty, b_ctr;
 	const size_t n_up_rows = U * n_upper_layers;
@@ -508,7 +515,6 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 	}
 	uint32_t h_ctr[4];
 	HIP_TRY(fh, hipMemcpy(h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost));
-	(void)hipStreamDestroy(st);
 	*max_layer_io = max_layer;
 	*starting_vertex_io = starting_vertex;
 	if (stats) {
