@@ -285,6 +285,27 @@ def bench_c4(a):
         sys.exit(rc)
 
 
+class _DeviceBytes:
+    """n bytes of device memory at `ptr` for torch.as_tensor (the CUDA array interface)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def gloo_exchange(torch, dist):
+    """expann_exchange_fn for the rehearsal (ranks sharing one GPU): the rank's chunk goes to the
+    host in stream order, gloo gathers, the gathered chunks go back on the same stream."""
+    def fn(d_send, d_recv, nbytes, rank, world, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            mine = torch.as_tensor(_DeviceBytes(d_send, nbytes), device="cuda").cpu()
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            torch.as_tensor(_DeviceBytes(d_recv, nbytes * world), device="cuda").copy_(torch.cat(parts))
+            torch.cuda.current_stream().synchronize()
+        return 0
+    return fn
+
+
 def main():
     a = parse()
     if a.workload == "c4":
@@ -313,9 +334,11 @@ def main():
     # rank grid: pure row sharding by default (every rank searches every query); R < G = hybrid grid
     from expann_amd.sharded import shard_range, shard_grid, ceil_shard_range
     R, Q = shard_grid(G, a.row_shards or G)       # rank = query group x row shard
-    native = G > 1 and R == G and not rehearsal and a.exchange in ("auto", "native")
+    # (rehearsal: ranks share a GPU, which RCCL refuses -- `--exchange native` then runs the same rank
+    # form of the C ABI with the all-gather handed in by the caller: expann_sharded_set_exchange_fn)
+    native = G > 1 and R == G and a.exchange in (("native",) if rehearsal else ("auto", "native"))
     if a.exchange == "native" and G > 1 and not native:
-        raise SystemExit("--exchange native needs pure row sharding on one GPU per rank")
+        raise SystemExit("--exchange native needs pure row sharding")
     row_idx, qgroup = rank % R, rank // R
     # rank r holds rows [r * ceil(N/R), min(N, (r+1) * ceil(N/R)))
     lo, hi = ceil_shard_range(a.n, row_idx, R)
@@ -364,10 +387,12 @@ def main():
         # torch.distributed, ncclCommInitRank / ncclAllGather / merge run inside libexpann_hip
         err = None
         try:
-            box = [ShardedBruteForceEngine.unique_id() if rank == 0 else None]
+            box = [ShardedBruteForceEngine.unique_id() if rank == 0 and not rehearsal else None]
             dist.broadcast_object_list(box, src=0)
             eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
                                           unique_id=box[0])
+            if rehearsal:
+                eng.set_exchange_fn(gloo_exchange(torch, dist))
             eng.set_shard_device(0, base.data_ptr(), hi - lo, lo)
         except Exception as e:   # (reported, never silent: config.sharding names the exchange that ran)
             err = e
@@ -599,6 +624,9 @@ def main():
         else:
             host_sync = "per step" + (" (this path checks its flags at once: exact-uint8 shortcut / retry)"
                                       if use_async else "")
+        exchange_name = ("torch.distributed all_gather + expann_merge_topk" if not native else
+                         ("the caller's all-gather (gloo) + merge behind the C ABI (expann_sharded_*)"
+                          if rehearsal else "RCCL all-gather + merge behind the C ABI (expann_sharded_*)"))
         out = {"metric": f"queries/sec at recall@{a.k}=1.0 (exact brute force), {shape}xd{a.d} {desc}, k={a.k}",
                "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -610,7 +638,7 @@ def main():
                           "host_sync": host_sync,
                           "sharding": (f"rows/{R} x queries/{Q}: rank r scans rows [r*ceil(N/{R}), ...) for "
                                        f"{'all' if Q == 1 else 'its slice of the'} queries; exchange = "
-                                       f"{'RCCL all-gather + merge behind the C ABI (expann_sharded_*)' if native else 'torch.distributed all_gather + expann_merge_topk'}"
+                                       f"{exchange_name}"
                                        f"; rank 0 scans {n_local} rows for {m_local} queries, roofline figures "
                                        f"are rank 0's launch") if G > 1 else "none"},
                "roofline": roofline}

@@ -29,10 +29,14 @@ ABI_SYMBOLS = [
     "expann_sharded_create", "expann_sharded_unique_id", "expann_sharded_create_rank",
     "expann_sharded_destroy", "expann_sharded_last_error", "expann_sharded_add", "expann_sharded_build",
     "expann_sharded_set_shard_device", "expann_sharded_size", "expann_sharded_shards",
-    "expann_sharded_exchange", "expann_sharded_search", "expann_sharded_search_device",
+    "expann_sharded_exchange", "expann_sharded_set_exchange_fn", "expann_sharded_search", "expann_sharded_search_device",
     "expann_sharded_sync", "expann_sharded_set_option", "expann_sharded_set_profiling",
     "expann_sharded_get_profile",
 ]
+
+
+# expann_exchange_fn(ctx, d_send, d_recv, bytes, rank, world, stream) -> 0 = ok
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 
 class Profile(C.Structure):
@@ -188,6 +192,8 @@ def load():
     L.expann_sharded_shards.argtypes = [vp]
     L.expann_sharded_exchange.restype = C.c_int
     L.expann_sharded_exchange.argtypes = [vp]
+    L.expann_sharded_set_exchange_fn.restype = C.c_int
+    L.expann_sharded_set_exchange_fn.argtypes = [vp, EXCHANGE_FN, vp]
     L.expann_sharded_search.restype = C.c_int
     L.expann_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp]
     L.expann_sharded_search_device.restype = C.c_int

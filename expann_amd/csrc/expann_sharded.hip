@@ -67,6 +67,8 @@ struct expann_sharded {
 	size_t elem = 4, q_elem = 4;
 	std::vector<Shard> shards;          // in-process: one per device; rank form: exactly one
 	int rank = 0, world = 1;            // rank form (in-process: world = shards in use)
+	expann_exchange_fn exchange_fn = nullptr;  // rank form: the caller's all-gather in place of RCCL's
+	void* exchange_ctx = nullptr;
 	bool rank_form = false;
 	std::vector<unsigned char> staging;  // add() rows until build()
 	size_t n_staged = 0, n_total = 0;
@@ -377,8 +379,8 @@ int expann_sharded_create_rank(int dim, int dtype, int metric, int device, int r
 	int rc = common_create(dim, dtype, metric, out, h);
 	if (rc != EXPANN_OK)
 		return rc;
-	if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) {
-		g_create_error = "expann_sharded_create_rank: bad rank / world / unique id";
+	if (world < 1 || rank < 0 || rank >= world) {
+		g_create_error = "expann_sharded_create_rank: bad rank / world";
 		delete h;
 		return EXPANN_ERR_INVALID_ARG;
 	}
@@ -392,7 +394,9 @@ int expann_sharded_create_rank(int dim, int dtype, int metric, int device, int r
 		expann_sharded_destroy(h);
 		return rc;
 	}
-	if (world > 1 || id128) {  // (a one-rank communicator when an id is given: the RCCL path on one GPU)
+	// no id: no RCCL communicator -- one rank needs none, more ranks exchange through the caller's
+	// function (expann_sharded_set_exchange_fn); a one-rank id gives the RCCL path on one GPU
+	if (id128) {
 		ncclUniqueId id;
 		std::memcpy(&id, id128, sizeof(id));
 		const ncclResult_t r = ncclCommInitRank(&h->shards[0].comm, world, id, rank);
@@ -535,7 +539,10 @@ int expann_sharded_search_device(expann_sharded* h, const void* d_queries, size_
 	HIP_TRY(h, hipSetDevice(s.device));
 	hipStream_t st = stream ? (hipStream_t)stream : s.stream;
 	h->searches++;
-	if (!s.comm) {  // one rank, no communicator: the local result is the result
+	if (!s.comm && !h->exchange_fn) {  // one rank, no communicator: the local result is the result
+		if (h->world > 1)
+			return h->fail(EXPANN_ERR_INVALID_ARG,
+			               "rank form without a unique id: set the exchange with expann_sharded_set_exchange_fn");
 		SUB_TRY(h, s, expann_search_device(s.idx, d_queries, m, k, d_ids, d_dists, st));
 		return EXPANN_OK;
 	}
@@ -549,11 +556,27 @@ int expann_sharded_search_device(expann_sharded* h, const void* d_queries, size_
 	}
 	SUB_TRY(h, s, expann_search_device(s.idx, d_queries, m, k, reinterpret_cast<uint64_t*>(s.mine),
 	                                   reinterpret_cast<float*>(s.mine + m * k * 8), st));
-	NCCL_TRY(h, ncclAllGather(s.mine, s.gathered, cb, ncclChar, s.comm, st));
+	if (h->exchange_fn) {
+		if (h->exchange_fn(h->exchange_ctx, s.mine, s.gathered, cb, h->rank, h->world, (void*)st) != 0)
+			return h->fail(EXPANN_ERR_HIP, "the caller's exchange function failed");
+	} else {
+		NCCL_TRY(h, ncclAllGather(s.mine, s.gathered, cb, ncclChar, s.comm, st));
+	}
 	if (expann_merge_topk_strided_device(s.device, reinterpret_cast<const uint64_t*>(s.gathered),
 	                                     reinterpret_cast<const float*>(s.gathered + m * k * 8), cb / 8, cb / 4,
 	                                     (size_t)h->world, m, k, d_ids, d_dists, st) != EXPANN_OK)
 		return h->fail(EXPANN_ERR_HIP, std::string("merge: ") + expann_last_error(nullptr));
+	return EXPANN_OK;
+}
+
+int expann_sharded_set_exchange_fn(expann_sharded* h, expann_exchange_fn fn, void* ctx) {
+	if (!h)
+		return EXPANN_ERR_INVALID_ARG;
+	if (!h->rank_form)
+		return h->fail(EXPANN_ERR_INVALID_ARG, "the in-process form exchanges between its own devices");
+	h->exchange_fn = fn;
+	h->exchange_ctx = ctx;
+	h->exchange_used = fn ? 3 : (h->shards[0].comm ? 1 : 0);
 	return EXPANN_OK;
 }
 

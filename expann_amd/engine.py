@@ -177,7 +177,7 @@ class ShardedBruteForceEngine:
 
     def param_list(self):
         return {"devices": ",".join(map(str, self.devices)), "shards": str(self.shards()),
-                "exchange": {0: "none", 1: "rccl", 2: "device copies"}[self.exchange()]}
+                "exchange": {0: "none", 1: "rccl", 2: "device copies", 3: "caller"}[self.exchange()]}
 
     def store_many_vectors(self, rows):
         rows = np.ascontiguousarray(rows, dtype=_NP_DTYPE[self.dtype])
@@ -217,6 +217,22 @@ class ShardedBruteForceEngine:
 
     def sync(self):
         self._check(self._L.expann_sharded_sync(self._h))
+
+    def set_exchange_fn(self, fn):
+        """Rank form: fn(d_send, d_recv, nbytes, rank, world, stream) -> 0 gathers every rank's chunk of
+        device memory (expann_sharded_set_exchange_fn) in place of RCCL's all-gather; None = RCCL again."""
+        if fn is None:
+            self._xfn = _lib.EXCHANGE_FN(0)
+        else:
+            def tramp(_ctx, d_send, d_recv, nbytes, rank, world, stream):
+                try:
+                    return int(fn(d_send or 0, d_recv or 0, nbytes, rank, world, stream or 0))
+                except Exception:  # (an exception cannot cross the C frames above this one)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._xfn = _lib.EXCHANGE_FN(tramp)  # (kept alive with the engine)
+        self._check(self._L.expann_sharded_set_exchange_fn(self._h, self._xfn, None))
 
     def set_option(self, name, value):
         self._check(self._L.expann_sharded_set_option(self._h, name.encode(), int(value)))

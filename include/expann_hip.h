@@ -143,7 +143,8 @@ int expann_sharded_create(int dim, int dtype, int metric, const int* devices, in
                           expann_sharded** out);
 /* One-process-per-GPU form: rank `rank` of `world` ranks on `device`; id128 = the 128 bytes rank 0
  * got from expann_sharded_unique_id (ncclGetUniqueId), distributed by the launcher.  Collective:
- * every rank calls it (ncclCommInitRank). */
+ * every rank calls it (ncclCommInitRank).  id128 == NULL: no RCCL communicator -- one rank needs
+ * none, more ranks exchange through expann_sharded_set_exchange_fn. */
 int expann_sharded_unique_id(void* id128);
 int expann_sharded_create_rank(int dim, int dtype, int metric, int device, int rank, int world,
                                const void* id128, expann_sharded** out);
@@ -160,7 +161,16 @@ int expann_sharded_set_shard_device(expann_sharded* h, int shard, const void* d_
                                     uint64_t id_offset);
 size_t expann_sharded_size(const expann_sharded* h);  /* rows over all local shards */
 int expann_sharded_shards(const expann_sharded* h);   /* shards in use (rank form: world) */
-int expann_sharded_exchange(const expann_sharded* h); /* 0 none (one shard), 1 RCCL, 2 device copies */
+int expann_sharded_exchange(const expann_sharded* h); /* 0 none (one shard), 1 RCCL, 2 device copies,
+                                                         3 the caller's function */
+/* Rank form: the all-gather of the per-rank result chunks through the caller's transport instead
+ * of RCCL (another fabric; ranks that share one GPU, which RCCL refuses; tests).  fn gathers
+ * `bytes` bytes of device memory d_send from every rank into d_recv (rank r's chunk at r * bytes)
+ * ordered after the work already on `stream` and complete, as far as `stream` is concerned, when it
+ * returns or in stream order; 0 = ok.  fn == NULL goes back to the communicator. */
+typedef int (*expann_exchange_fn)(void* ctx, const void* d_send, void* d_recv, size_t bytes, int rank,
+                                  int world, void* stream);
+int expann_sharded_set_exchange_fn(expann_sharded* h, expann_exchange_fn fn, void* ctx);
 /* in-process form, host buffers: as expann_search. */
 int expann_sharded_search(expann_sharded* h, const void* queries, size_t m, size_t k, uint64_t* ids,
                           float* dists);
