@@ -30,6 +30,7 @@
 #include "scan_gemm_i8.hpp"
 #include "scan_gemm_i8q.hpp"
 #include "scan_gemm_i8x.hpp"
+#include "scan_gemm_i8w.hpp"
 #include "scan_int8.hpp"
 #include "score_ids.hpp"
 #include "select.hpp"
@@ -139,6 +140,7 @@ struct expann_index {
 	                                 // full scan drowned in candidates (90 k instead of 2.8 M QPS on
 	                                 // 1000 contiguous clusters); on iid rows the two differ by < 1 %
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
+	long opt_i8w = 1;                // 8-bit rows, d = 128 / 256: scan_gemm_i8w.hpp (16x16x64, f16x's step, hit logs)
 	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
 	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
@@ -638,6 +640,54 @@ void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t s
 	}
 }
 
+// Per-wave hit logs of the scans that write them (scan_gemm_f16x.hpp, scan_gemm_i8w.hpp): one log
+// per wave of the grid, together as large as the candidate lists they are filed into; the launch
+// geometry is kept for launch_gather_logs.
+int ensure_hit_logs(expann_index* h, uint32_t grid, int waves, size_t m, uint32_t cap, uint32_t n_chunks,
+                    uint32_t n_qtiles, uint32_t xcd_map, hipStream_t st, uint4** log, uint32_t** log_cnt,
+                    uint32_t* log_cap_out) {
+	const uint32_t n_logs = grid * (uint32_t)waves;
+	const uint32_t log_cap = std::max<uint32_t>(
+	    1024, pow2ceil((uint32_t)std::min<size_t>((m * (size_t)cap + n_logs - 1) / n_logs, 1u << 20)));
+	const size_t need = (size_t)n_logs * log_cap * 16;
+	if (need > h->log_bytes || n_logs > h->log_cnt_n) {
+		HIP_TRY(h, hipStreamSynchronize(st));
+		h->d_log.reset();
+		h->d_log_cnt.reset();
+		h->log_bytes = h->log_cnt_n = 0;
+		HIP_TRY(h, hipMalloc(&h->d_log, need));
+		HIP_TRY(h, hipMalloc(&h->d_log_cnt, sizeof(uint32_t) * n_logs));
+		h->log_bytes = need;
+		h->log_cnt_n = n_logs;
+	}
+	*log = h->d_log.as<uint4>();
+	*log_cnt = h->d_log_cnt;
+	*log_cap_out = log_cap;
+	h->pending_scatter.n_logs = n_logs;
+	h->pending_scatter.log_cap = log_cap;
+	h->pending_scatter.cap = cap;
+	h->pending_scatter.n_chunks = n_chunks;
+	h->pending_scatter.n_qtiles = n_qtiles;
+	h->pending_scatter.xcd_map = xcd_map;
+	h->pending_scatter.m = (uint32_t)m;
+	return EXPANN_OK;
+}
+
+// after a scan that wrote hit logs: file them into the per-query candidate lists
+void launch_gather_logs(expann_index* h, hipStream_t st) {
+	if (!h->pending_scatter.n_logs)
+		return;
+	const auto ps = h->pending_scatter;
+	h->pending_scatter.n_logs = 0;
+	// ~1024 workgroups: the logs of a (query tile, wave) pair are split over n_groups of them
+	const uint32_t want = std::max<uint32_t>(1, (1024 + ps.n_qtiles * 4 - 1) / (ps.n_qtiles * 4));
+	const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
+	const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
+	GatherLogParams gp{h->d_log.as<const uint4>(), h->d_log_cnt.as<const uint32_t>(), ps.log_cap, ps.n_chunks,
+	                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
+	hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
+}
+
 // Deferred check: the flag block of this search goes to the next ring slot and the call returns
 // without waiting; expann_sync looks at the slots.  False when the caller has to wait as usual.
 bool defer_flags(expann_index* h, hipStream_t st, int attempt) {
@@ -711,6 +761,9 @@ struct GemmI8qVariant {
 	const char* name;
 	int dq;  // physical row bytes of the engine's copy (> d: zero-padded, scan_gemm_i8q.hpp)
 	int lds, threads, wg_per_cu;
+	// scan_gemm_i8w.hpp: the full scan writes per-wave hit logs (gather_logs_kernel files them)
+	void (*scan_w)(GemmI8wParams) = nullptr;
+	int lds_w = 0, threads_w = 0, wg_per_cu_w = 0;
 };
 #define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false>, \
 	scan_gemm_i8q_kernel<DQ, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
@@ -736,6 +789,14 @@ const GemmI8qVariant kGemmI8x[] = {
     GEMM_I8X_P(960, 1024, kU8L2, true, "U8L2"), GEMM_I8X_P(960, 1024, kI8L2, true, "I8L2"),
     GEMM_I8X_P(960, 1024, kI8IP, false, "I8IP")};
 #undef GEMM_I8X_P
+// d = 128 / 256: f16x's step structure on 16x16x64 with hit logs (scan_gemm_i8w.hpp)
+#define GEMM_I8W(D, MODE, L2F, MN) {D, MODE, nullptr, scan_gemm_i8q_kernel<D, L2F, true>, row_self_i8_kernel<D, MODE>, \
+	query_theta_i8_kernel<D, MODE>, "scan_gemm_i8w<" #D "," MN ">", D, gemm_i8q_lds_bytes<D>(), kF16Threads, \
+	I8wGeom<D>::WG_PER_CU, scan_gemm_i8w_kernel<D, L2F>, gemm_i8w_lds_bytes<D>(), kF16Threads, I8wGeom<D>::WG_PER_CU}
+const GemmI8qVariant kGemmI8w[] = {
+    GEMM_I8W(128, kU8L2, true, "U8L2"), GEMM_I8W(128, kI8L2, true, "I8L2"), GEMM_I8W(128, kI8IP, false, "I8IP"),
+    GEMM_I8W(256, kU8L2, true, "U8L2"), GEMM_I8W(256, kI8L2, true, "I8L2"), GEMM_I8W(256, kI8IP, false, "I8IP")};
+#undef GEMM_I8W
 #undef GEMM_I8Q
 #undef GEMM_I8Q_P
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
@@ -748,6 +809,10 @@ const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
 		return nullptr;
 	if (h->n < 2 * 256 * kF16TB || k > 256)
 		return nullptr;
+	if (h->opt_i8w)
+		for (const auto& v : kGemmI8w)
+			if (v.d == h->dim && v.mode == h->int_mode)
+				return &v;
 	if (h->opt_i8x)
 		for (const auto& v : kGemmI8x)
 			if (v.d == h->dim && v.mode == h->int_mode)
@@ -897,25 +962,47 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		fp.cand_cnt = h->d_cnt;
 		fp.cand = h->d_cand;
 		fp.cap = cap;
-		uint32_t fchunks = pick_row_chunks(nt, nqt, wg_slots, 4.0, 8, 2048, h->opt_xcd_tolerance,
+		// (a retry after overflowed logs / lists goes to the direct appends of scan_gemm_i8q)
+		const GemmI8qVariant* gs = gq;
+		if (gq->scan_w && attempt > 0)
+			for (const auto& v : kGemmI8q)
+				if (v.d == gq->d && v.mode == gq->mode)
+					gs = &v;
+		const uint32_t scan_slots = gs->scan_w ? (uint32_t)gs->wg_per_cu_w * (uint32_t)cus : wg_slots;
+		uint32_t fchunks = pick_row_chunks(nt, nqt, scan_slots, 4.0, 8, 2048, h->opt_xcd_tolerance,
 		                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
 		fp.tiles_per_block = (nt + fchunks - 1) / fchunks;
 		fchunks = (nt + fp.tiles_per_block - 1) / fp.tiles_per_block;
 		const bool timed = h->profiling && h->ev_used < kEventPairs;
 		if (timed)
 			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-		hipLaunchKernelGGL(gq->scan, dim3(fchunks * nqt), wg, lds, st, fp);
+		if (gs->scan_w) {
+			GemmI8wParams wp{};
+			wp.q = fp;
+			// (four logs per workgroup: one per 64 queries of its tile)
+			rc = ensure_hit_logs(h, fchunks * nqt, 4, m, cap, fchunks, nqt, fp.xcd_map, st, &wp.log, &wp.log_cnt,
+			                     &wp.log_cap);
+			if (rc != EXPANN_OK)
+				return rc;
+			wp.lost = h->d_overflow;
+			if (timed)  // (ensure_hit_logs may have waited for the stream: stamp again)
+				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+			hipLaunchKernelGGL(gs->scan_w, dim3(fchunks * nqt), dim3((uint32_t)gs->threads_w), gs->lds_w, st, wp);
+		} else {
+			hipLaunchKernelGGL(gs->scan, dim3(fchunks * nqt), dim3((uint32_t)gs->threads), gs->lds, st, fp);
+		}
 		if (timed) {
 			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 			h->ev_used++;
 		}
+		launch_gather_logs(h, st);
 		if (timed || !h->profiling) {
 			h->prof.scan_launches++;
 			h->prof.scan_rows += h->n;
 			h->prof.scan_query_tiles += nqt;
 			h->prof.query_tile = kF16TQ;
 			h->prof.levels = 2;
-			std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", gq->name);
+			std::snprintf(h->prof.scan_kernel, sizeof(h->prof.scan_kernel), "%s", gs->name);
 		}
 		HIP_TRY(h, hipGetLastError());
 		mark("scan");
@@ -1213,32 +1300,11 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 	} else {
 		const uint32_t grid = fchunks * fp.n_qtiles;
 		if (gvf->hit_log) {
-			// one log per wave, together as large as the candidate lists they are filed into
-			const uint32_t n_logs = grid * (uint32_t)(gvf->threads / 64);
-			const uint32_t log_cap = std::max<uint32_t>(1024, pow2ceil((uint32_t)std::min<size_t>(
-			                                                      (m * (size_t)cap + n_logs - 1) / n_logs, 1u << 20)));
-			const size_t need = (size_t)n_logs * log_cap * 16;
-			if (need > h->log_bytes || n_logs > h->log_cnt_n) {
-				HIP_TRY(h, hipStreamSynchronize(st));
-				h->d_log.reset();
-				h->d_log_cnt.reset();
-				h->log_bytes = h->log_cnt_n = 0;
-				HIP_TRY(h, hipMalloc(&h->d_log, need));
-				HIP_TRY(h, hipMalloc(&h->d_log_cnt, sizeof(uint32_t) * n_logs));
-				h->log_bytes = need;
-				h->log_cnt_n = n_logs;
-			}
-			fp.log = h->d_log.as<uint4>();
-			fp.log_cnt = h->d_log_cnt;
-			fp.log_cap = log_cap;
+			const int lrc = ensure_hit_logs(h, grid, gvf->threads / 64, m, cap, fchunks, fp.n_qtiles, fp.xcd_map, st,
+			                                &fp.log, &fp.log_cnt, &fp.log_cap);
+			if (lrc != EXPANN_OK)
+				return lrc;
 			fp.lost = h->d_overflow;
-			h->pending_scatter.n_logs = n_logs;
-			h->pending_scatter.log_cap = log_cap;
-			h->pending_scatter.cap = cap;
-			h->pending_scatter.n_chunks = fchunks;
-			h->pending_scatter.n_qtiles = fp.n_qtiles;
-			h->pending_scatter.xcd_map = fp.xcd_map;
-			h->pending_scatter.m = (uint32_t)m;
 		}
 		hipLaunchKernelGGL(gvf->scan, dim3(grid), dim3((uint32_t)gvf->threads), gvf->lds, st, fp);
 		*kname = gvf->name;
@@ -1604,17 +1670,7 @@ int SearchPass::run_level(size_t li) {
 		HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 		h->ev_used++;
 	}
-	if (h->pending_scatter.n_logs) {  // scan_gemm_f16x: file the per-wave hit logs into the lists
-		const auto ps = h->pending_scatter;
-		h->pending_scatter.n_logs = 0;
-		// ~1024 workgroups: the logs of a (query tile, wave) pair are split over n_groups of them
-		const uint32_t want = std::max<uint32_t>(1, (1024 + ps.n_qtiles * 4 - 1) / (ps.n_qtiles * 4));
-		const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
-		const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
-		GatherLogParams gp{h->d_log.as<const uint4>(), h->d_log_cnt.as<const uint32_t>(), ps.log_cap, ps.n_chunks,
-		                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
-		hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
-	}
+	launch_gather_logs(h, st);
 	if (last && (timed || !h->profiling)) {
 		h->prof.scan_launches++;
 		h->prof.scan_rows += h->n;
@@ -1911,6 +1967,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		h->opt_f16x = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_I8X"))
 		h->opt_i8x = std::atol(e);
+	if (const char* e = std::getenv("EXPANN_I8W"))
+		h->opt_i8w = std::atol(e);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -1957,6 +2015,14 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		if (v.d == dim &&
 		    hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess) {
 			g_create_error = "hipFuncSetAttribute(scan_gemm_i8x_kernel) failed";
+			hipStreamDestroy(h->stream);
+			delete h;
+			return EXPANN_ERR_HIP;
+		}
+	for (const auto& v : kGemmI8w)
+		if (v.d == dim &&
+		    hipFuncSetAttribute((const void*)v.scan_w, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_w) != hipSuccess) {
+			g_create_error = "hipFuncSetAttribute(scan_gemm_i8w_kernel) failed";
 			hipStreamDestroy(h->stream);
 			delete h;
 			return EXPANN_ERR_HIP;
@@ -2402,6 +2468,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_f16x = value;
 	else if (!std::strcmp(name, "i8x"))
 		h->opt_i8x = value;
+	else if (!std::strcmp(name, "i8w"))
+		h->opt_i8w = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

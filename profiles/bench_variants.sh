@@ -18,6 +18,8 @@ run --n 1000000 --d 64 --k 10 --steps 10
 run --n 1000000 --dtype u8 --steps 10
 run --n 1000000 --dtype i8 --metric ip --steps 10
 run --n 1000000 --d 256 --dtype i8 --steps 10
+run --n 1000000 --d 256 --steps 10
+run --n 1000000 --d 512 --steps 5
 run --n 1000000 --d 768 --steps 3
 run --n 1000000 --d 832 --steps 3
 run --n 1000000 --d 960 --steps 3

@@ -162,8 +162,33 @@ def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
     eng.set_option("scan_kernel", 5)
     eng.set_profiling(True)
     _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
-    # (d >= 768: the 16x16x64 form scan_gemm_i8x of the same geometry, scan_gemm_i8x.hpp)
-    assert eng.get_profile()["scan_kernel"].startswith(("scan_gemm_i8q", "scan_gemm_i8x")), eng.get_profile()["scan_kernel"]
+    # (d >= 768: the 16x16x64 form scan_gemm_i8x of the same geometry, scan_gemm_i8x.hpp; d = 128 / 256:
+    # scan_gemm_i8w, the 16x16x64 form in scan_gemm_f16x's step structure with hit logs)
+    want = "scan_gemm_i8x" if d >= 768 else "scan_gemm_i8w"
+    assert eng.get_profile()["scan_kernel"].startswith(want), eng.get_profile()["scan_kernel"]
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,metric,ometric,d", [("u8", "l2", "METRIC_L2_U8", 128), ("i8", "ip", "METRIC_IP_I8", 128),
+                                                     ("i8", "l2", "METRIC_L2_I8", 256), ("u8", "l2", "METRIC_L2_U8", 768)])
+def test_gemm_form_int8_32x32_kernels(oracle, dtype, metric, ometric, d):
+    """options i8w = 0 / i8x = 0: round 1's 32x32x32 kernels (scan_gemm_i8q) stay selectable and exact"""
+    i8w, kernel = 0, "scan_gemm_i8q"
+    n, m, k = 70001, 300, 17
+    rng = np.random.RandomState(d + 5)
+    if dtype == "u8":
+        base = _sift_like(rng, n, d).astype(np.uint8)
+        queries = _sift_like(rng, m, d).astype(np.float32)
+    else:
+        base = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
+        queries = rng.randint(-128, 128, size=(m, d)).astype(np.int8)
+    eng = _engine(base, metric, dtype)
+    eng.set_option("scan_kernel", 5)
+    eng.set_option("i8w", i8w)
+    eng.set_option("i8x", 0)
+    eng.set_profiling(True)
+    _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
+    assert eng.get_profile()["scan_kernel"].startswith(kernel), eng.get_profile()["scan_kernel"]
     eng.close()
 
 
