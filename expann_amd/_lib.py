@@ -80,15 +80,20 @@ def _one_hip_runtime():
     if not spec or not spec.origin:
         return
     tlib = os.path.join(os.path.dirname(spec.origin), "lib")
+    # (librccl.so is bundled the same way.  It is NOT opened here: pulled in ahead of torch's own load
+    # order it brings torch's rocm_smi / roctx copies with it and the process then aborts in its exit
+    # handlers ("double free or corruption", measured).  Library first + torch second therefore
+    # leaves two independent RCCL copies -- the library's communicators in /opt/rocm's, torch's in its
+    # own -- which works; torch first, as bench.py imports, gives one.)
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         p = os.path.join(tlib, name)
         if os.path.exists(p):
             C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
-def hip_runtimes_mapped():
-    """Distinct libamdhip64 files mapped into this process (must be 1 once the library is loaded)."""
-    return sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+def hip_runtimes_mapped(stem="libamdhip64"):
+    """Distinct libamdhip64 (or `stem`) files mapped into this process (must be 1 once the library is loaded)."""
+    return sorted({ln.split()[-1] for ln in open("/proc/self/maps") if stem in ln})
 
 
 def load():
