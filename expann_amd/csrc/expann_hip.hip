@@ -743,12 +743,19 @@ uint32_t pick_row_chunks(uint32_t n_tiles, uint32_t n_qtiles, uint32_t slots, do
 // scan (~1.2 k frac per query) grow with it.  Measured optima: 12-16 at k = 10 (flat), 8 at
 // k = 100 (3.44 ms per 2500 queries x 5 M rows against 3.65 at 5 and 3.62 at 16).
 // (8-bit forms: the scan is twice as fast, the candidates cost the same: 5 at k = 100.)
+// The sample's cost grows with the bytes of the index, the candidates' does not, so the optimum
+// moves up on the largest shapes (profiles/sweep_frac_big.sh, ab_frac.sh: C5 = 30 x C2's bytes: 48
+// is 3-4 % faster than 16, 96 overflows the lists; 10 M x d128: +1.7 %): ~bytes^0.3 from 8 x C2's
+// bytes on, k <= 32 (between C2 and that, and at k = 100, the denser hits cost the scan what the
+// sample saves: 1 M x d960, 4 M x d128, 10 M x d128 k = 100 all within +-1 %).
 uint32_t sample_frac_for(const expann_index* h, size_t k) {
 	if (h->opt_sample_frac > 0)
 		return (uint32_t)h->opt_sample_frac;
 	const double expo = h->dtype == EXPANN_DTYPE_F32 ? 0.3 : 0.5;
-	const double f = 16.0 * std::pow(10.0 / (double)std::max<size_t>(1, k), expo);
-	return (uint32_t)std::min(32.0, std::max(4.0, std::round(f)));
+	const double bytes = (double)h->n * (double)h->dim * (h->dtype == EXPANN_DTYPE_F32 ? 2.0 : 1.0);
+	const double size = (bytes >= 8 * 2.56e8 && k <= 32) ? std::min(3.0, std::pow(bytes / 2.56e8, 0.3)) : 1.0;
+	const double f = 16.0 * std::pow(10.0 / (double)std::max<size_t>(1, k), expo) * size;
+	return (uint32_t)std::min(48.0, std::max(4.0, std::round(f)));
 }
 
 // ---- 8-bit GEMM form, queue geometry (scan_gemm_i8q.hpp), d = 128 / 256 / 768 / 832 / 960 -----
