@@ -1286,8 +1286,8 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 	fp.debug = (uint32_t)h->opt_debug & ~16u;
 	DevBuf clk;
 	if (h->opt_debug & 16) {
-		HIP_TRY(h, clk.alloc(18 * 8));
-		HIP_TRY(h, hipMemsetAsync(clk.p, 0, 18 * 8, st));
+		HIP_TRY(h, clk.alloc((18 + 3 * 65536) * 8));  // (+ per-workgroup records of scan_gemm_f16x)
+		HIP_TRY(h, hipMemsetAsync(clk.p, 0, (18 + 3 * 65536) * 8, st));
 		fp.clk = clk.as<unsigned long long>();
 	}
 	const DirectF16Variant* dv =
@@ -1329,6 +1329,20 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 		if (c[6])
 			std::fprintf(stderr, "  per step (%llu steps): columns 0-1 %.0f, stage wait + barrier %.0f, columns 2-3 %.0f, tail + queue work %.0f cycles\n",
 			             c[6], (double)c[2] / c[6], (double)c[3] / c[6], (double)c[4] / c[6], (double)c[5] / c[6]);
+		if (const char* dump = std::getenv("EXPANN_WG_TIMES")) {  // per-workgroup start / end / place, for profiles/wg_times.py
+			const uint32_t grid = std::min<uint32_t>(fchunks * fp.n_qtiles, 65536);
+			std::vector<unsigned long long> rec(3 * (size_t)grid);
+			HIP_TRY(h, hipMemcpy(rec.data(), fp.clk + 18, rec.size() * 8, hipMemcpyDeviceToHost));
+			if (FILE* f = std::fopen(dump, "w")) {
+				for (uint32_t b = 0; b < grid; ++b)
+					std::fprintf(f, "%u %llu %llu %llu\n", b, rec[3 * b], rec[3 * b + 1], rec[3 * b + 2]);
+				std::fclose(f);
+			}
+		}
+		if (c[14])  // (scan_gemm_f16x: the last workgroup of the grid as well)
+			std::fprintf(stderr, "scan_gemm_f16 last wg: %llu shader clocks in %.1f us = %.0f MHz, started %.1f us after wg0; per step (%llu): %.0f / %.0f / %.0f / %.0f\n",
+			             c[8], c[9] / 100.0, c[9] ? c[8] * 100.0 / c[9] : 0.0, (double)(c[15] - c[7]) / 100.0, c[14],
+			             (double)c[10] / c[14], (double)c[11] / c[14], (double)c[12] / c[14], (double)c[13] / c[14]);
 	}
 	return EXPANN_OK;
 }

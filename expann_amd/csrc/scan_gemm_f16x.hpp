@@ -379,12 +379,23 @@ __global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16x_kernel(GemmF16P
 			atomicAdd(p.lost, 1u);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (p.clk && blockIdx.x == 0 && tid == 0) {
-		p.clk[0] = clock64() - clk0;
-		p.clk[1] = wall_clock64() - wall0;
+	if (p.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {
+		unsigned long long* c = p.clk + (blockIdx.x == 0 ? 0 : 8);  // (first and last workgroup of the grid)
+		c[0] = clock64() - clk0;
+		c[1] = wall_clock64() - wall0;
 		for (int i = 0; i < 4; ++i)
-			p.clk[2 + i] = seg[i];
-		p.clk[6] = t1 - t0;
+			c[2 + i] = seg[i];
+		c[6] = t1 - t0;
+		c[7] = wall0;
+	}
+	if (p.clk && tid == 0) {  // (debug 16: every workgroup's start / end on the 100 MHz clock, and its CU)
+		p.clk[18 + 3 * (size_t)blockIdx.x] = wall0;
+		p.clk[19 + 3 * (size_t)blockIdx.x] = wall_clock64();
+		uint32_t hwid;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+		uint32_t xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		p.clk[20 + 3 * (size_t)blockIdx.x] = ((unsigned long long)xcc << 32) | hwid;
 	}
 }
 
