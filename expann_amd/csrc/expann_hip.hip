@@ -414,10 +414,10 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 // the 16x16x32 form of the full scan (scan_gemm_f16x.hpp); its sampled pass is the 32x32x16 kernel's
 #define F16X_V(D)                                                                                  \
 	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,           \
-	 f16_query_prep_kernel<D>, "scan_gemm_f16x<" #D ", false>", kF16TB, kF16TQ, kF16Threads, 2,      \
-	 gemm_f16x_lds_bytes<D>(), 1}
-// (d = 64 measured slower on this form than on scan_gemm_f16_kernel<64>'s three workgroups per CU:
-// 6.55 M vs 6.83 M QPS at 1 M rows -- two k-steps per column leave too little MFMA per step)
+	 f16_query_prep_kernel<D>, "scan_gemm_f16x<" #D ", false>", kF16TB, kF16TQ, kF16Threads,         \
+	 f16x_wg_per_cu<D>(), gemm_f16x_lds_bytes<D>(), 1}
+// (d = 64 with two workgroups per CU measured slower than scan_gemm_f16_kernel<64>'s three: 6.55 M vs
+// 6.83 M QPS at 1 M rows -- two k-steps per column leave too little MFMA per step; hence three here too)
 // d = 256 / 512: the 8-waves-per-tile geometry on 16x16x32 (scan_gemm_f16y.hpp), hits appended directly
 #define F16Y_V(D)                                                                                  \
 	{D, scan_gemm_f16y_kernel<D>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
@@ -428,7 +428,7 @@ const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(5
 	{D, scan_gemm_f16kx_kernel<D>, scan_gemm_f16k_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
 	 "scan_gemm_f16kx<" #D ", false>", F16kGeom<D>::TB, F16kGeom<D>::WGQ, F16kGeom<D>::THREADS, 1,     \
 	 F16kGeom<D>::LDS_BYTES, 0}
-const GemmF16Variant kGemmF16X[] = {F16X_V(128), F16Y_V(256), F16Y_V(512), F16KX_V(768), F16KX_V(832), F16KX_V(960)};
+const GemmF16Variant kGemmF16X[] = {F16X_V(64), F16X_V(128), F16Y_V(256), F16Y_V(512), F16KX_V(768), F16KX_V(832), F16KX_V(960)};
 #undef F16KX_V
 #undef F16Y_V
 #undef F16X_V
@@ -2016,8 +2016,9 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 				return EXPANN_ERR_HIP;
 			}
 	for (const auto& v : kGemmF16X)
-		if (v.d == dim &&
-		    hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess) {
+		if (v.d == dim &&  // (the sampled pass is launched with the scan's LDS size, never less than its own)
+		    (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess ||
+		     hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess)) {
 			g_create_error = "hipFuncSetAttribute(scan_gemm_f16x_kernel) failed";
 			hipStreamDestroy(h->stream);
 			delete h;

@@ -28,24 +28,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // staging, 4 no epilogue, 8 no candidate path, 32 no LDS fragment reads, 64 flushes drop their hits);
 // the production instance has none of their branches, so a step's MFMA stream is ONE basic block.
 // LDS of one workgroup: tiles + per-wave bn' slots + per-wave queues + theta' + queue fills
+// d = 64: two k-steps per column are too little MFMA per step for two waves per SIMD (measured: 4 %
+// slower than scan_gemm_f16_kernel<64>), so -- as scan_gemm_i8w_kernel<128>, the same byte geometry --
+// the form stays under 168 VGPRs there and runs THREE workgroups per CU (smaller hit queues to fit)
+template <int D> constexpr int f16x_qcap() { return D == 64 ? 64 : kF16WaveQueue; }
+template <int D> constexpr int f16x_wg_per_cu() { return D == 64 ? 3 : 2; }
 template <int D> constexpr int gemm_f16x_lds_bytes() {
-	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) + kF16Waves * kF16WaveQueue * kF16EntryBytes + kF16TQ * 4 + 64;
+	return kF16Bufs * (kF16TB * D * 2 + kF16Waves * 256) + kF16Waves * f16x_qcap<D>() * kF16EntryBytes + kF16TQ * 4 + 64;
 }
+static_assert(gemm_f16x_lds_bytes<64>() * 3 <= 160 * 1024, "three workgroups per CU at d = 64");
 static_assert(gemm_f16x_lds_bytes<128>() == gemm_f16_lds_bytes<128>(), "same LDS map as scan_gemm_f16_kernel<128>");
 
 template <int D, bool SAMPLE, int DBG = 0>
-__global__ __launch_bounds__(kF16Threads, 2) void scan_gemm_f16x_kernel(GemmF16Params p) {
+__global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f16x_kernel(GemmF16Params p) {
 	const uint32_t dbg = DBG ? p.debug : 0u;
 	static_assert(D == 64 || D == 128, "built for d = 64, 128");
 	using G = F16Geom<128>;  // (geometry of the 4-wave form; d = 64 shares it here: no TH_LDS variant)
-	constexpr int THREADS = kF16Threads, WAVES = kF16Waves, WGQ = kF16TQ, QCAP = kF16WaveQueue;
+	constexpr int THREADS = kF16Threads, WAVES = kF16Waves, WGQ = kF16TQ, QCAP = f16x_qcap<D>();
 	constexpr int ROWB = D * 2, CH = ROWB / 16;
 	constexpr int KS = D / 32;  // MFMA k-steps of 32
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
 	constexpr int NBUF = kF16Bufs, PF = NBUF - 1;
-	static_assert(G::NBUF == NBUF && G::QCAP == QCAP && G::WGQ == WGQ, "shares gemm_f16_lds_bytes<128>()");
+	static_assert(G::NBUF == NBUF && G::WGQ == WGQ && (D == 64 || G::QCAP == QCAP), "shares gemm_f16_lds_bytes<128>()");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const int tid = threadIdx.x;
