@@ -743,6 +743,9 @@ uint32_t pick_row_chunks(uint32_t n_tiles, uint32_t n_qtiles, uint32_t slots, do
 // scan (~1.2 k frac per query) grow with it.  Measured optima: 12-16 at k = 10 (flat), 8 at
 // k = 100 (3.44 ms per 2500 queries x 5 M rows against 3.65 at 5 and 3.62 at 16).
 // (8-bit forms: the scan is twice as fast, the candidates cost the same: 5 at k = 100.)
+// Round 2, scan_gemm_f16x with hit logs, C3's per-GPU shape (profiles/sweep_frac_k100.sh): 4, 6 and 8
+// are even at k = 100 (3.69-3.70 ms per step: scan 2.67 / 2.80 / 2.91 ms at 468 / 703 / 922 candidates per
+// query, ~55 cycles of a workgroup per hit), 10 and up lose (12: 4.17 ms; 24 overflows the lists).
 // The sample's cost grows with the bytes of the index, the candidates' does not, so the optimum
 // moves up on the largest shapes (profiles/sweep_frac_big.sh, ab_frac.sh: C5 = 30 x C2's bytes: 48
 // is 3-4 % faster than 16, 96 overflows the lists; 10 M x d128: +1.7 %): ~bytes^0.3 from 8 x C2's
