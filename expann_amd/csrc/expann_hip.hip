@@ -983,24 +983,22 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
 		fp.tiles_per_block = (nt + fchunks - 1) / fchunks;
 		fchunks = (nt + fp.tiles_per_block - 1) / fp.tiles_per_block;
-		const bool timed = h->profiling && h->ev_used < kEventPairs;
-		if (timed)
-			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-		if (gs->scan_w) {
-			GemmI8wParams wp{};
+		GemmI8wParams wp{};
+		if (gs->scan_w) {  // four hit logs per workgroup, one per 64 queries of its tile (may wait for the stream to grow them)
 			wp.q = fp;
-			// (four logs per workgroup: one per 64 queries of its tile)
 			rc = ensure_hit_logs(h, fchunks * nqt, 4, m, cap, fchunks, nqt, fp.xcd_map, st, &wp.log, &wp.log_cnt,
 			                     &wp.log_cap);
 			if (rc != EXPANN_OK)
 				return rc;
 			wp.lost = h->d_overflow;
-			if (timed)  // (ensure_hit_logs may have waited for the stream: stamp again)
-				HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
-			hipLaunchKernelGGL(gs->scan_w, dim3(fchunks * nqt), dim3((uint32_t)gs->threads_w), gs->lds_w, st, wp);
-		} else {
-			hipLaunchKernelGGL(gs->scan, dim3(fchunks * nqt), dim3((uint32_t)gs->threads), gs->lds, st, fp);
 		}
+		const bool timed = h->profiling && h->ev_used < kEventPairs;
+		if (timed)
+			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][0], st));
+		if (gs->scan_w)
+			hipLaunchKernelGGL(gs->scan_w, dim3(fchunks * nqt), dim3((uint32_t)gs->threads_w), gs->lds_w, st, wp);
+		else
+			hipLaunchKernelGGL(gs->scan, dim3(fchunks * nqt), dim3((uint32_t)gs->threads), gs->lds, st, fp);
 		if (timed) {
 			HIP_TRY(h, hipEventRecord(h->ev[h->ev_used][1], st));
 			h->ev_used++;
