@@ -140,6 +140,7 @@ struct expann_index {
 	                                 // full scan drowned in candidates (90 k instead of 2.8 M QPS on
 	                                 // 1000 contiguous clusters); on iid rows the two differ by < 1 %
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
+	long opt_tail_chunks = 1;        // scan_gemm_f16x: the last round's row chunks three times finer (pick_tail_chunks)
 	long opt_i8w = 1;                // 8-bit rows, d = 128 / 256: scan_gemm_i8w.hpp (16x16x64, f16x's step, hit logs)
 	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
 	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
@@ -739,6 +740,36 @@ uint32_t pick_row_chunks(uint32_t n_tiles, uint32_t n_qtiles, uint32_t slots, do
 	return chunks;
 }
 
+// Two chunk sizes for a launch of several rounds (scan_gemm_f16x): workgroups are dispatched in block
+// order and a launch ends when its last workgroup does, so with equal chunks the last round drains
+// for about half a workgroup's time (profiles/wg_times.py: 480 of 512 resident on average at C2).
+// The chunks of all rounds but the last stay as they are; the rows of the last round are cut three
+// times finer.  Both counts are multiples of 8 (xcd_map).  Returns false when the launch is too
+// short to gain (fewer than 3 rounds) or the chunk count does not suit.
+bool pick_tail_chunks(uint32_t n_tiles, uint32_t g, uint32_t n_qtiles, uint32_t slots, uint32_t min_tiles,
+                      uint32_t* tiles_big, uint32_t* n_big, uint32_t* tiles_small, uint32_t* n_small) {
+	const uint64_t rounds = ((uint64_t)g * n_qtiles + slots - 1) / slots;
+	if (rounds < 3 || g % 8 != 0 || g < 24)
+		return false;
+	uint32_t nb = (uint32_t)(((rounds - 1) * slots / n_qtiles) / 8) * 8;  // chunks of the first rounds - 1 rounds
+	nb = std::min(nb, g - 8);
+	if (nb < 8)
+		return false;
+	const uint32_t ns = (3 * (g - nb) + 7) / 8 * 8;
+	const uint32_t big = (uint32_t)(((uint64_t)n_tiles * 3 + (3 * nb + ns) - 1) / (3 * nb + ns));  // big = 3 small
+	if ((uint64_t)nb * big >= n_tiles)
+		return false;
+	const uint32_t rest = n_tiles - nb * big;
+	const uint32_t small = (rest + ns - 1) / ns;
+	if (small < min_tiles || (uint64_t)(ns - 1) * small >= rest)  // (every small chunk must hold rows)
+		return false;
+	*tiles_big = big;
+	*n_big = nb;
+	*tiles_small = small;
+	*n_small = ns;
+	return true;
+}
+
 // Rows read by the sampled pass = 1/frac.  Its cost falls with frac, the candidates of the full
 // scan (~1.2 k frac per query) grow with it.  Measured optima: 12-16 at k = 10 (flat), 8 at
 // k = 100 (3.44 ms per 2500 queries x 5 M rows against 3.65 at 5 and 3.62 at 16).
@@ -1277,6 +1308,17 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 	}
 	fp.tiles_per_block = (fp.n_tiles_sel + fchunks - 1) / fchunks;
 	fchunks = (fp.n_tiles_sel + fp.tiles_per_block - 1) / fp.tiles_per_block;
+	if (gvf->hit_log && fp.xcd_map && h->opt_tail_chunks && !h->opt_scan_chunks) {  // (scan_gemm_f16x reads n_big)
+		uint32_t big, nb, small, ns;
+		// (small chunks of >= 64 steps: at 40 -- 500 k rows -- their prologues cost more than the drain saves)
+		if (pick_tail_chunks(fp.n_tiles_sel, fchunks, fp.n_qtiles, (uint32_t)gvf->wg_per_cu * (uint32_t)cus, 64, &big, &nb,
+		                     &small, &ns)) {
+			fp.tiles_per_block = big;
+			fp.n_big = nb;
+			fp.tiles_small = small;
+			fchunks = nb + ns;
+		}
+	}
 	fp.queries_f16 = h->d_q_split;
 	fp.theta = h->d_theta;
 	fp.two_inv_s2 = (ip ? 1.0f : 2.0f) / (h->f16_scale * h->f16_scale);
@@ -1991,6 +2033,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		h->opt_i8x = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_I8W"))
 		h->opt_i8w = std::atol(e);
+	if (const char* e = std::getenv("EXPANN_TAIL_CHUNKS"))
+		h->opt_tail_chunks = std::atol(e);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -2493,6 +2537,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_i8x = value;
 	else if (!std::strcmp(name, "i8w"))
 		h->opt_i8w = value;
+	else if (!std::strcmp(name, "tail_chunks"))
+		h->opt_tail_chunks = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

@@ -215,6 +215,10 @@ struct GemmF16Params {
 	// {x, x+8, ...} and all their query tiles go to XCD x, so a tile is fetched into ONE L2
 	// instead of eight.  Needs the chunk count to be a multiple of 8.
 	uint32_t xcd_map;
+	// scan_gemm_f16x_kernel only: row chunks of two sizes.  Chunks 0 .. n_big - 1 hold tiles_per_block
+	// tiles, the chunks behind them tiles_small (0 = one size).  Workgroups start in block order, so
+	// the launch ends on the small ones and drains in a third of the time (pick_tail_chunks).
+	uint32_t n_big, tiles_small;
 	// scan_gemm_f16x_kernel only: every wave appends its hits to a log of its own in global memory --
 	// log[(4 blockIdx.x + wave) * log_cap + i] = {key, query}, plain stores in the wave's own order, no
 	// atomic and no returned value to wait for inside the MFMA kernel -- and leaves the count in

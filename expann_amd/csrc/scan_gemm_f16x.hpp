@@ -68,8 +68,12 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	const uint32_t wg_q0 = qtile * WGQ;
 	const uint32_t q0 = wg_q0 + wave * 64;
 
-	const uint32_t t0 = chunk * p.tiles_per_block;
+	uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
+	if (p.tiles_small && chunk >= p.n_big) {  // the launch's tail: smaller chunks (GemmF16Params::n_big)
+		t0 = p.n_big * p.tiles_per_block + (chunk - p.n_big) * p.tiles_small;
+		t1 = t0 + p.tiles_small;
+	}
 	if (t1 > p.n_tiles_sel)
 		t1 = p.n_tiles_sel;
 	uint32_t* const my_log_cnt = p.log_cnt + (size_t)blockIdx.x * WAVES + wave;
