@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "i8", "u8"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4"],
                     help="preset: c2 = BASELINE configs[1] (default, the headline metric); "
+                         "c3 = configs[2] 10Mxd128 fp32, k=100 (sets n / k; with --gpus G the rows are "
+                         "sharded G ways as the config asks, one GPU holds all 10 M); "
                          "c5 = configs[4] int8 IP 10Mxd768 (sets n/d/dtype/metric); "
                          "c4 = configs[3] graph search recall sweep (SIFT-like stand-in, --rows rows, "
                          "M=60 / M0=120 / ef_construction=480, built by the batched GPU builder)")
@@ -88,6 +90,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="rough budget of the CPU baseline leg")
     a = ap.parse_args()
+    if a.workload == "c3":
+        if a.n == 1_000_000:
+            a.n = 10_000_000
+        if a.k == 10:
+            a.k = 100
     if a.workload == "c5":
         a.dtype, a.metric = "i8", "ip"
         if a.n == 1_000_000 and a.d == 128:
@@ -637,7 +644,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"brute_force_engine {a.metric.upper()} N={a.n} d={a.d} {desc}, "
                                       f"{a.m} batched queries, k={a.k} (BASELINE "
-                                      f"{'configs[1]' if a.workload == 'c2' else 'configs[4]'})",
+                                      f"{ {'c2': 'configs[1]', 'c3': 'configs[2]', 'c5': 'configs[4]'}[a.workload]})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
                           "host_sync": host_sync,
                           "sharding": (f"rows/{R} x queries/{Q}: rank r scans rows [r*ceil(N/{R}), ...) for "

@@ -28,4 +28,5 @@ run --n 1000000 --d 960 --dtype u8 --steps 3
 run --n 1000000 --d 832 --dtype u8 --steps 3
 run --n 1000000 --k 10 --m 1 --steps 50
 run --n 1000000 --k 10 --m 4 --steps 50
+run --workload c3 --steps 3
 run --workload c5 --steps 3
