@@ -68,3 +68,53 @@ def test_random_configuration_matches_the_oracle(oracle, seed):
     eng.close()
     assert np.array_equal(ids, rids), (dtype, metric, n, d, m, k)
     assert np.array_equal(dists.view(np.uint32), rd.view(np.uint32)), (dtype, metric, n, d, m, k)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EXPANN_FUZZ_MFMA_N", "24"))))
+def test_random_mfma_configuration_matches_the_oracle(oracle, seed):
+    """The same sweep with every case large enough for the matrix-core filters (>= 65 536 rows, >= 97
+    queries): fp16 forms at d = 64 ... 960, int8 forms at d = 128 ... 960, their sampled passes, hit
+    logs / queues, overflow retries with tiny lists; except on massive-tie data the kernel that ran must
+    be one of the GEMM forms."""
+    from expann_amd import GpuBruteForceEngine
+    rng = np.random.RandomState(50_000 + seed)
+    dtype = rng.choice(["f32", "f32", "u8", "i8"])
+    d = int(rng.choice([64, 128, 256, 512, 768, 832, 960] if dtype == "f32" else [128, 256, 768, 832, 960]))
+    n = int(rng.choice([70001, 131072, 200000]))
+    m = int(rng.choice([97, 130, 300, 700]))
+    k = int(rng.choice([1, 10, 10, 17, 64, 100]))
+    metric = "l2"
+    if dtype == "f32":
+        metric = str(rng.choice(["l2", "l2", "ip"]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "scaled"]))
+        base = _data(rng, kind, n, d)
+        queries = _data(rng, kind if kind != "dups" else "gauss", m, d)
+        if kind == "dups":
+            queries[0] = base[0]
+        ometric = oracle.METRIC_L2_F32 if metric == "l2" else oracle.METRIC_IP_F32
+    elif dtype == "u8":
+        base = np.clip(np.round(np.abs(rng.standard_normal((n, d))) * 40), 0, 255).astype(np.uint8)
+        queries = np.clip(np.round(np.abs(rng.standard_normal((m, d))) * 40), 0, 255).astype(np.float32)
+        ometric = oracle.METRIC_L2_U8
+    else:
+        metric = str(rng.choice(["l2", "ip"]))
+        base = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
+        queries = rng.randint(-128, 128, size=(m, d)).astype(np.int8)
+        ometric = oracle.METRIC_L2_I8 if metric == "l2" else oracle.METRIC_IP_I8
+    eng = GpuBruteForceEngine(d, metric, dtype)
+    eng.store_many_vectors(base)
+    eng.build()
+    eng.set_profiling(True)
+    if rng.rand() < 0.2:
+        eng.set_option("cand_capacity", int(rng.choice([256, 1024])))
+    if rng.rand() < 0.2:
+        eng.set_option("sample_frac", int(rng.choice([4, 32])))
+    ids, dists = eng.query_k_batch(queries, k)
+    kernel = eng.get_profile()["scan_kernel"]
+    rids, rd = oracle.brute_force(base, queries, k, ometric, n_threads=16)
+    eng.close()
+    assert np.array_equal(ids, rids), (dtype, metric, n, d, m, k, kernel)
+    assert np.array_equal(dists.view(np.uint32), rd.view(np.uint32)), (dtype, metric, n, d, m, k, kernel)
+    # (massive ties -- "dups" -- may end on the exact direct kernel, which breaks them by row number)
+    if not (dtype == "f32" and kind == "dups"):
+        assert kernel.startswith("scan_gemm_"), (dtype, metric, n, d, m, k, kernel)
