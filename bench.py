@@ -63,6 +63,9 @@ def parse():
                     help="native: RCCL all-gather + merge behind the C ABI (expann_sharded_*; default for "
                          "pure row sharding); torch: the same exchange through torch.distributed "
                          "(always for the hybrid grid and the one-GPU rehearsal)")
+    ap.add_argument("--exchange-pattern", default="auto", choices=["auto", "allgather", "slices"],
+                    help="sharded handle (expann_sharded_*): slices (= auto) -- all-to-all of query slices, each "
+                         "rank merges m/G queries; allgather -- round 2's one all-gather of whole chunks")
     ap.add_argument("--verify-queries", type=int, default=0,
                     help="queries of the step checked against the CPU oracle when no cpu_baseline leg "
                          "runs (G > 1 or --no-cpu-baseline); default 8, 0 with --no-verify")
@@ -313,17 +316,66 @@ def gloo_exchange(torch, dist):
     return fn
 
 
+def gloo_alltoallv(torch, dist):
+    """expann_alltoallv_fn for the rehearsal: the query slices of exchange pattern 2 over gloo (which has
+    no all-to-all: one isend / irecv per peer), staged through the host in stream order."""
+    def fn(d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes, rank, world, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            ops, landed = [], []
+            for j in range(world):
+                if send_bytes[j]:
+                    part = torch.as_tensor(_DeviceBytes(d_send + send_off[j], send_bytes[j]), device="cuda").cpu()
+                    ops.append(dist.P2POp(dist.isend, part, j))
+                if recv_bytes[j]:
+                    buf = torch.empty(recv_bytes[j], dtype=torch.uint8)
+                    landed.append((j, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, j))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for j, buf in landed:
+                torch.as_tensor(_DeviceBytes(d_recv + recv_off[j], recv_bytes[j]), device="cuda").copy_(buf)
+            torch.cuda.current_stream().synchronize()
+        return 0
+    return fn
+
+
+def fail(msg, code=5):
+    print(f"bench: {msg}", file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
 def main():
     a = parse()
     if a.workload == "c4":
         return bench_c4(a)
     import numpy as np
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = bool(os.environ.get("EXPANN_BENCH_REHEARSAL"))
+    G = a.gpus
+    if G < 1:
+        fail("--gpus must be >= 1")
+    # ---- how the G GPUs are driven: never fewer than asked for, never silently ----------------------
+    #   launched by torch.distributed.run (WORLD_SIZE = G): one rank per GPU, the rank form of the C ABI
+    #   launched plainly with --gpus G > 1: ONE process drives the G devices through the in-process
+    #   handle (expann_sharded_create(devices 0..G-1), ncclCommInitAll: SURVEY 8e's form)
+    if world > 1 and world != G:
+        fail(f"WORLD_SIZE={world} but --gpus {G}: launch `python -m torch.distributed.run --nproc-per-node {G} "
+             f"bench.py --gpus {G}` or plain `python bench.py --gpus {G}`")
+    inproc = world == 1 and G > 1
+    from expann_amd import _lib
+    n_dev = _lib.load().expann_device_count()
+    need = G if inproc else (local_rank + 1 if world > 1 else 1)
+    if n_dev < 1:
+        fail(f"no HIP device visible; --gpus {G} needs {G} (libexpann_hip has no CPU fallback)")
+    if n_dev < need and not rehearsal:
+        fail(f"--gpus {G} but only {n_dev} HIP device(s) visible"
+             + ("" if inproc else f" (this is local rank {local_rank})")
+             + "; set EXPANN_BENCH_REHEARSAL=1 to let the shards share devices (a rehearsal, not a measurement)")
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -332,8 +384,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    G = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from expann_amd import GpuBruteForceEngine, ShardedBruteForceEngine
@@ -341,35 +391,45 @@ def main():
     # rank grid: pure row sharding by default (every rank searches every query); R < G = hybrid grid
     from expann_amd.sharded import shard_range, shard_grid, ceil_shard_range
     R, Q = shard_grid(G, a.row_shards or G)       # rank = query group x row shard
+    if inproc and R != G:
+        fail("the in-process form shards rows only (launch with torch.distributed.run for --row-shards)")
     # (rehearsal: ranks share a GPU, which RCCL refuses -- `--exchange native` then runs the same rank
-    # form of the C ABI with the all-gather handed in by the caller: expann_sharded_set_exchange_fn)
-    native = G > 1 and R == G and a.exchange in (("native",) if rehearsal else ("auto", "native"))
-    if a.exchange == "native" and G > 1 and not native:
+    # form of the C ABI with the exchange handed in by the caller: expann_sharded_set_*_fn)
+    native = world > 1 and R == G and a.exchange in (("native",) if rehearsal else ("auto", "native"))
+    if a.exchange == "native" and world > 1 and not native:
         raise SystemExit("--exchange native needs pure row sharding")
-    row_idx, qgroup = rank % R, rank // R
+    row_idx, qgroup = (0, 0) if inproc else (rank % R, rank // R)
     # rank r holds rows [r * ceil(N/R), min(N, (r+1) * ceil(N/R)))
     lo, hi = ceil_shard_range(a.n, row_idx, R)
     q_lo, q_hi = shard_range(a.m, qgroup, Q)
     m_local, pad = q_hi - q_lo, (a.m + Q - 1) // Q
+    pattern_opt = {"auto": 0, "allgather": 1, "slices": 2}[a.exchange_pattern]
 
     # synthetic data, iid N(0,1), un-normalised (src/randomgeometry.h:87-95); fixed seeds
-    g = torch.Generator(device=dev)
+    gens = {}
 
-    def make_rows(r_idx):
+    def gen_on(device):
+        if device not in gens:
+            gens[device] = torch.Generator(device=device)
+        return gens[device]
+
+    def make_rows(r_idx, device=dev):
         r_lo, r_hi = ceil_shard_range(a.n, r_idx, R)
+        g = gen_on(device)
         g.manual_seed(1234 + r_idx)
         if a.dtype == "f32":
-            b = torch.randn(r_hi - r_lo, a.d, device=dev, dtype=torch.float32, generator=g)
+            b = torch.randn(r_hi - r_lo, a.d, device=device, dtype=torch.float32, generator=g)
             if a.sift_like:
                 b = b.abs_().mul_(40).round_().clamp_(0, 255)
             return b
         if a.dtype == "i8":   # int8 uniform in [-127, 127]
-            return torch.randint(-127, 128, (r_hi - r_lo, a.d), device=dev, dtype=torch.int8, generator=g)
+            return torch.randint(-127, 128, (r_hi - r_lo, a.d), device=device, dtype=torch.int8, generator=g)
         # SURVEY 8d C4 stand-in: clamp(round(|N(0,1)|*40), 0, 255)
-        return torch.randn(r_hi - r_lo, a.d, device=dev, generator=g).abs_().mul_(40).round_() \
+        return torch.randn(r_hi - r_lo, a.d, device=device, generator=g).abs_().mul_(40).round_() \
             .clamp_(0, 255).to(torch.uint8)
 
     base = make_rows(row_idx)
+    g = gen_on(dev)
     g.manual_seed(4321)
     if a.dtype == "f32":
         queries = torch.randn(a.m, a.d, device=dev, dtype=torch.float32, generator=g)
@@ -389,31 +449,84 @@ def main():
             .clamp_(0, 255).to(torch.float32)
 
     eng = None
-    if native:
+    ip_state = None     # in-process form: per-shard tensors
+    if inproc:
+        # ONE process, G devices behind one handle; shard r's rows are generated on ITS device and adopted
+        devices = [i % n_dev for i in range(G)]
+        eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, devices=devices)
+        bases, qs = [], []
+        for r in range(G):
+            d_r = torch.device("cuda", devices[r])
+            r_lo, r_hi = ceil_shard_range(a.n, r, R)
+            if r_hi == r_lo:
+                break       # (the ceil partition left this and the later shards without rows)
+            with torch.cuda.device(d_r):
+                b_r = base if (r == 0 and d_r == dev) else make_rows(r, d_r)
+                bases.append(b_r)
+                eng.set_shard_device(r, b_r.data_ptr(), r_hi - r_lo, r_lo)
+                qs.append(queries if d_r == dev else queries.to(d_r))
+        if pattern_opt:
+            eng.set_option("exchange_pattern", pattern_opt)
+        G_act = eng.shards()
+        outs = []
+        for r in range(G_act):
+            s_lo, s_hi = eng.slice(a.m, r)
+            with torch.cuda.device(devices[r]):
+                outs.append((torch.empty(max(1, s_hi - s_lo), a.k, dtype=torch.int64, device=qs[r].device),
+                             torch.empty(max(1, s_hi - s_lo), a.k, dtype=torch.float32, device=qs[r].device)))
+        for d_i in sorted(set(devices)):
+            torch.cuda.synchronize(d_i)
+        ip_state = (devices, bases, qs, outs, G_act)
+    elif native:
         # one process per GPU, the exchange behind the C ABI: rank 0's RCCL unique id travels over
-        # torch.distributed, ncclCommInitRank / ncclAllGather / merge run inside libexpann_hip
-        err = None
-        try:
-            box = [ShardedBruteForceEngine.unique_id() if rank == 0 and not rehearsal else None]
-            dist.broadcast_object_list(box, src=0)
-            eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
-                                          unique_id=box[0])
-            if rehearsal:
-                eng.set_exchange_fn(gloo_exchange(torch, dist))
-            eng.set_shard_device(0, base.data_ptr(), hi - lo, lo)
-        except Exception as e:   # (reported, never silent: config.sharding names the exchange that ran)
-            err = e
-        bad = torch.tensor([1 if err is not None else 0], device=dev, dtype=torch.int32)
+        # torch.distributed, ncclCommInitRank / the collectives / merge run inside libexpann_hip.
+        # Every rank makes the SAME sequence of torch collectives whatever fails where: (1) rank 0's id --
+        # or its failure -- is broadcast; (2) a flag is reduced BEFORE anyone enters ncclCommInitRank
+        # (a rank that cannot take part would leave its peers blocked inside it); (3) one more after.
+        pre_err = None
+        box = [None]
+        if rank == 0 and not rehearsal:
+            try:
+                box = [ShardedBruteForceEngine.unique_id()]
+            except Exception as e:
+                box = [("unique_id failed", str(e))]
+        dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], tuple):
+            pre_err = f"rank 0: {box[0][0]}: {box[0][1]}"
+        try:    # this rank's own device is usable (what expann_sharded_create_rank does before the collective)
+            probe = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
+            probe.close()
+        except Exception as e:
+            pre_err = pre_err or f"rank {rank}: {e}"
+        bad = torch.tensor([1 if pre_err else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        err = pre_err
+        if not int(bad.item()):
+            try:
+                eng = ShardedBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank, rank=rank, world=G,
+                                              unique_id=box[0])
+                if rehearsal:
+                    eng.set_exchange_fn(gloo_exchange(torch, dist))
+                    eng.set_alltoallv_fn(gloo_alltoallv(torch, dist))
+                if pattern_opt:
+                    eng.set_option("exchange_pattern", pattern_opt)
+                eng.set_shard_device(0, base.data_ptr() if hi > lo else 0, hi - lo, lo)
+            except Exception as e:   # (reported, never silent: config.sharding names the exchange that ran)
+                err = str(e)
+            bad = torch.tensor([1 if err else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad.item()):
             if a.exchange == "native":
-                raise SystemExit(f"--exchange native failed: {err}")
-            print(f"bench: native RCCL exchange unavailable on some rank ({err}); using torch.distributed",
-                  file=sys.stderr)
+                raise SystemExit(f"--exchange native failed: {err or 'on another rank'}")
+            print(f"bench: native RCCL exchange unavailable on some rank ({err or 'another rank'}); "
+                  "using torch.distributed", file=sys.stderr)
             if eng is not None:
                 eng.close()
             eng, native = None, False
     if eng is None:
+        if hi == lo:
+            fail(f"rank {rank} holds no rows (N = {a.n} over {R} row shards): only the native exchange "
+                 "(the rank form of the C ABI) takes empty shards")
         eng = GpuBruteForceEngine(a.d, a.metric, a.dtype, device=local_rank)
         eng.set_base_device(base.data_ptr(), hi - lo, lo)
     for name, val in (("query_tile", a.query_tile), ("scan_kernel", a.scan_kernel), ("debug", a.debug),
@@ -433,10 +546,9 @@ def main():
     work_stream = torch.cuda.Stream(device=dev)
     stream = work_stream.cuda_stream
     use_async = not a.sync_search
-    if use_async:
-        # deferred check: a search is enqueued without a host wait, so the next kernels / the RCCL
-        # exchange are already queued when it ends; expann_sync validates all steps at the end
-        eng.set_option("async_search", 1)
+    # deferred check: a search is enqueued without a host wait, so the next kernels / the RCCL
+    # exchange are already queued when it ends; expann_sync validates all steps at the end
+    eng.set_option("async_search", 1 if use_async else 0)
     cb = chunk_bytes(pad, a.k)
 
     def alloc(name, nbytes, like):
@@ -457,16 +569,62 @@ def main():
         merge_topk_strided_device(local_rank, gp, gp + rows * k * 8, cb // 8, cb // 4, n_lists, rows, k,
                                   op, op + rows * k * 8, stream)
 
-    if native:
+    def sync_devices():
+        if inproc:
+            for d_i in sorted(set(ip_state[0])):
+                torch.cuda.synchronize(d_i)
+        else:
+            torch.cuda.synchronize()
+
+    if inproc:
+        devices, bases, qs, outs, G_act = ip_state
+        q_ptrs = [q.data_ptr() for q in qs]
+        i_ptrs = [o[0].data_ptr() for o in outs]
+        d_ptrs = [o[1].data_ptr() for o in outs]
+
+        def step():
+            # every shard's scan, the exchange and the merge of its query slice: enqueued on all G devices
+            # (one host thread per device inside the library), nothing waits
+            eng.search_devices(q_ptrs, a.m, a.k, i_ptrs, d_ptrs)
+            return None, None
+
+        def collect():
+            parts = [eng.slice(a.m, r) for r in range(G_act)]
+            ids = torch.cat([outs[r][0][:b - c].to(dev) for r, (c, b) in enumerate(parts)], 0)
+            dd = torch.cat([outs[r][1][:b - c].to(dev) for r, (c, b) in enumerate(parts)], 0)
+            return ids, dd
+    elif native:
         out_ids = torch.empty(a.m, a.k, dtype=torch.int64, device=dev)
         out_d = torch.empty(a.m, a.k, dtype=torch.float32, device=dev)
 
         def step():
-            # local scan, ncclAllGather, merge: all enqueued on `stream` by the library
+            # local scan, exchange, merge: all enqueued on `stream` by the library
             eng.search_device(queries.data_ptr(), a.m, a.k, out_ids.data_ptr(), out_d.data_ptr(), stream)
             return out_ids, out_d
+    elif world > 1 and R == G and pattern_opt == 2:
+        # --exchange torch --exchange-pattern slices: pattern 2 through torch.distributed
+        from expann_amd.sharded import SliceShardedSearch
+
+        def merge_slices(l_ids, l_d, n_lists, per, cnt, k, o_ids, o_d):
+            merge_topk_strided_device(local_rank, l_ids.data_ptr(), l_d.data_ptr(), per * k, per * k, n_lists, cnt, k,
+                                      o_ids.data_ptr(), o_d.data_ptr(), stream)
+
+        def local_all(q, k, chunk):
+            p0 = chunk.data_ptr()
+            eng.search_device(q.data_ptr(), q.shape[0], k, p0, p0 + q.shape[0] * k * 8, stream)
+
+        def alloc_plain(name, nbytes, like):
+            if name not in bufs:
+                bufs[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            return bufs[name]
+
+        ss = SliceShardedSearch(dist, world, rank, local_all, merge_slices, alloc_plain)
+
+        def step():
+            with torch.cuda.stream(work_stream):
+                return ss.search(queries, a.k)
     else:
-        ss = GridShardedSearch(dist if G > 1 else None, G, rank, R, local_search, merge, alloc)
+        ss = GridShardedSearch(dist if world > 1 else None, world, rank, R, local_search, merge, alloc)
 
         def step():
             with torch.cuda.stream(work_stream):
@@ -475,9 +633,9 @@ def main():
     def timed(n_steps):
         """(seconds, ok): ok is False when a deferred search of the loop needed the synchronous
         retry (agreed between the ranks: every rank then repeats the steps the waiting way)"""
-        if G > 1:
+        if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_devices()
         t_start = time.perf_counter()
         for _ in range(n_steps):
             step()
@@ -488,12 +646,12 @@ def main():
             except RuntimeError as e:
                 print(f"bench: {e}", file=sys.stderr)
                 ok = False
-        torch.cuda.synchronize()
-        if G > 1:
+        sync_devices()
+        if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t_start
-        if G > 1:
-            flag = torch.tensor([0 if ok else 1], device=dev, dtype=torch.int32)
+        if world > 1:
+            flag = torch.tensor([0 if ok else 1], device="cpu" if rehearsal else dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             ok = int(flag.item()) == 0
         return dt, ok
@@ -513,22 +671,28 @@ def main():
         eng.get_profile()
         timed(1)
         elapsed, _ = timed(a.steps)
-    if G > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.get_profile()
+    enqueue_ms = eng.last_enqueue_ms() if inproc else None
     eng.set_profiling(False)
     # one more step, outside the timed region, whose result the checks below look at (it is the
     # same search on the same inputs as every timed step)
     got_ids, got_d = step()
     if use_async:
         eng.sync()
-    torch.cuda.synchronize()
+    sync_devices()
+    if inproc:
+        got_ids, got_d = collect()
     got_ids, got_d = got_ids[:a.m], got_d[:a.m]
 
     def whole_base():
-        return base if R == 1 else torch.cat([base if r == row_idx else make_rows(r) for r in range(R)], 0)
+        if R == 1:
+            return base
+        return torch.cat([base if r == row_idx else make_rows(r) for r in range(R)
+                          if ceil_shard_range(a.n, r, R)[1] > ceil_shard_range(a.n, r, R)[0]], 0)
 
     if a.verify and G > 1:
         if rank == 0:
@@ -635,9 +799,20 @@ def main():
         else:
             host_sync = "per step" + (" (this path checks its flags at once: exact-uint8 shortcut / retry)"
                                       if use_async else "")
-        exchange_name = ("torch.distributed all_gather + expann_merge_topk" if not native else
-                         ("the caller's all-gather (gloo) + merge behind the C ABI (expann_sharded_*)"
-                          if rehearsal else "RCCL all-gather + merge behind the C ABI (expann_sharded_*)"))
+        sharded_handle = inproc or native
+        transport = {0: "none", 1: "RCCL", 2: "device copies (shards share a device)",
+                     3: "the caller's transport (gloo)"}[eng.exchange()] if sharded_handle else "torch.distributed"
+        pattern = {0: "none", 1: "one all-gather of whole [m][k] chunks, every rank merges all queries",
+                   2: "all-to-all of query slices, each rank merges m/G queries"
+                      + ("" if inproc else ", all-gather of the merged slices")}[eng.exchange_pattern()] \
+            if sharded_handle else "all_gather + expann_merge_topk"
+        launch = ("one process, one handle over all devices (expann_sharded_create, ncclCommInitAll; one enqueue "
+                  "thread per device)" if inproc else
+                  ("one rank per GPU (torch.distributed.run), the rank form of the C ABI "
+                   "(expann_sharded_create_rank, ncclCommInitRank)" if native else
+                   ("one rank per GPU (torch.distributed.run), exchange through torch.distributed" if world > 1
+                    else "one process, one GPU")))
+        rows_per_rank = [ceil_shard_range(a.n, r, R)[1] - ceil_shard_range(a.n, r, R)[0] for r in range(R)]
         out = {"metric": f"queries/sec at recall@{a.k}=1.0 (exact brute force), {shape}xd{a.d} {desc}, k={a.k}",
                "value": round(qps, 1), "unit": "queries/s", "n_gpus": G, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -647,12 +822,22 @@ def main():
                                       f"{ {'c2': 'configs[1]', 'c3': 'configs[2]', 'c5': 'configs[4]'}[a.workload]})",
                           "n": a.n, "d": a.d, "m": a.m, "k": a.k, "metric": a.metric,
                           "host_sync": host_sync,
+                          "launch": launch,
+                          "devices_visible": n_dev,
+                          # the communicator's size as RCCL itself reports it (ncclCommCount); 0 = no RCCL communicator
+                          "comm_ranks": (eng.comm_ranks() if sharded_handle else (world if world > 1 and not rehearsal else 0)),
+                          "rows_per_rank": rows_per_rank if G > 1 else [a.n],
                           "sharding": (f"rows/{R} x queries/{Q}: rank r scans rows [r*ceil(N/{R}), ...) for "
-                                       f"{'all' if Q == 1 else 'its slice of the'} queries; exchange = "
-                                       f"{exchange_name}"
-                                       f"; rank 0 scans {n_local} rows for {m_local} queries, roofline figures "
-                                       f"are rank 0's launch") if G > 1 else "none"},
-               "roofline": roofline}
+                                       f"{'all' if Q == 1 else 'its slice of the'} queries; transport = {transport}; "
+                                       f"exchange = {pattern}; rank 0 scans {n_local} rows for {m_local} queries, "
+                                       f"roofline figures are rank 0's launch") if G > 1 else "none"},
+               "roofline": roofline,
+               "verified_step": "one extra step after the timed loop (the same search on the same inputs)"}
+        if rehearsal:
+            out["config"]["rehearsal"] = ("EXPANN_BENCH_REHEARSAL: shards / ranks share the visible GPU(s); "
+                                          "a functional rehearsal, not a multi-GPU measurement")
+        if enqueue_ms is not None:
+            out["config"]["host_enqueue_ms_per_step"] = round(enqueue_ms, 4)
         # ---- the bench proves its own claim: GPU result vs the CPU oracle -----------------------
         checked = None
         mname = {("f32", "l2"): "METRIC_L2_F32", ("f32", "ip"): "METRIC_IP_F32",
@@ -672,7 +857,11 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))
                 import oracle_ctypes as oc
                 if base_host is None:
-                    base_host, queries_host = whole_base().cpu().numpy(), queries.cpu().numpy()
+                    if inproc:
+                        base_host = np.concatenate([b.cpu().numpy() for b in ip_state[1]], 0)
+                    else:
+                        base_host = whole_base().cpu().numpy()
+                    queries_host = queries.cpu().numpy()
                 checked = oc.brute_force(base_host, queries_host[:nv], a.k, getattr(oc, mname),
                                          min(nv, os.cpu_count() or 1))
             except Exception as e:
@@ -690,7 +879,7 @@ def main():
                 rc = 4
         print(json.dumps(out), flush=True)
     eng.close()
-    if G > 1:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rc:

@@ -31,12 +31,17 @@ ABI_SYMBOLS = [
     "expann_sharded_set_shard_device", "expann_sharded_size", "expann_sharded_shards",
     "expann_sharded_exchange", "expann_sharded_set_exchange_fn", "expann_sharded_search", "expann_sharded_search_device",
     "expann_sharded_sync", "expann_sharded_set_option", "expann_sharded_set_profiling",
-    "expann_sharded_get_profile",
+    "expann_sharded_get_profile", "expann_sharded_exchange_pattern", "expann_sharded_comm_ranks",
+    "expann_sharded_last_enqueue_ms", "expann_sharded_set_alltoallv_fn", "expann_sharded_search_devices",
+    "expann_sharded_slice",
 ]
 
 
 # expann_exchange_fn(ctx, d_send, d_recv, bytes, rank, world, stream) -> 0 = ok
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+# expann_alltoallv_fn(ctx, d_send, send_off[], send_bytes[], d_recv, recv_off[], recv_bytes[], rank, world, stream)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p,
+                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_void_p)
 
 
 class Profile(C.Structure):
@@ -199,6 +204,18 @@ def load():
     L.expann_sharded_exchange.argtypes = [vp]
     L.expann_sharded_set_exchange_fn.restype = C.c_int
     L.expann_sharded_set_exchange_fn.argtypes = [vp, EXCHANGE_FN, vp]
+    L.expann_sharded_set_alltoallv_fn.restype = C.c_int
+    L.expann_sharded_set_alltoallv_fn.argtypes = [vp, ALLTOALLV_FN, vp]
+    L.expann_sharded_exchange_pattern.restype = C.c_int
+    L.expann_sharded_exchange_pattern.argtypes = [vp]
+    L.expann_sharded_comm_ranks.restype = C.c_int
+    L.expann_sharded_comm_ranks.argtypes = [vp]
+    L.expann_sharded_last_enqueue_ms.restype = C.c_double
+    L.expann_sharded_last_enqueue_ms.argtypes = [vp]
+    L.expann_sharded_search_devices.restype = C.c_int
+    L.expann_sharded_search_devices.argtypes = [vp, C.POINTER(vp), sz, sz, C.POINTER(vp), C.POINTER(vp)]
+    L.expann_sharded_slice.restype = C.c_int
+    L.expann_sharded_slice.argtypes = [vp, sz, C.c_int, C.POINTER(sz), C.POINTER(sz)]
     L.expann_sharded_search.restype = C.c_int
     L.expann_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp]
     L.expann_sharded_search_device.restype = C.c_int

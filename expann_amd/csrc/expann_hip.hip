@@ -324,7 +324,20 @@ std::vector<Level> plan_levels(size_t n, size_t k, uint32_t cap, long ratio_opt)
 	return lv;
 }
 
+// grow one of the handle's shared buffers; deferred searches still in flight read the old block, so
+// their stream is drained first (hipFree happens to synchronise the device: stated, not implied)
+template <typename T> hipError_t grow_ws(expann_index* h, GrowPtr<T>& b, size_t need) {
+	if (h->async_pending > 0 && (need > b.bytes || !b.p)) {
+		const hipError_t e = hipStreamSynchronize(h->async_stream);
+		if (e != hipSuccess)
+			return e;
+	}
+	return b.ensure(need);
+}
+
 int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
+	if (h->async_pending > 0 && m > h->m_alloc)  // (the per-query arrays below: as grow_ws)
+		HIP_TRY(h, hipStreamSynchronize(h->async_stream));
 	if (m > h->m_alloc) {  // the per-query arrays grow together
 		h->m_alloc = 0;
 		for (DevPtr<float>* b : {std::addressof(h->d_qnrm), std::addressof(h->d_theta), std::addressof(h->d_tau[0]),
@@ -341,7 +354,7 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		HIP_TRY(h, hipMalloc(&h->d_qself, sizeof(int) * m));
 		h->m_alloc = m;
 	}
-	HIP_TRY(h, h->d_cand.ensure(sizeof(uint64_t) * m * (size_t)cap));
+	HIP_TRY(h, grow_ws(h, h->d_cand, sizeof(uint64_t) * m * (size_t)cap));
 	if (!h->d_overflow) {
 		// flags [4 x u32] and statistics [2 x u64] share one allocation: one memset, one read-back
 		HIP_TRY(h, hipMalloc(&h->d_overflow, sizeof(uint32_t) * 4 + sizeof(unsigned long long) * 2));
@@ -922,7 +935,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	const void* q8 = d_queries;
 	if (gq->dq != h->dim) {  // rows of the padded geometry: queries padded (and mapped) the same way
 		const size_t nb = m * (size_t)gq->dq;
-		HIP_TRY(h, h->d_q_split.ensure(nb));
+		HIP_TRY(h, grow_ws(h, h->d_q_split, nb));
 		hipLaunchKernelGGL(i8q_pad_rows_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, m, (uint32_t)h->dim / 4,
 		                   (uint32_t)gq->dq / 4, m, h->int_mode == kU8L2 ? 0x80808080u : 0u,
@@ -930,7 +943,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		q8 = h->d_q_split;
 	} else if (h->int_mode == kU8L2) {  // queries ^ 0x80 (d_queries is the uint8 conversion, d_q8)
 		const size_t nb = m * (size_t)h->dim;
-		HIP_TRY(h, h->d_q_split.ensure(nb));
+		HIP_TRY(h, grow_ws(h, h->d_q_split, nb));
 		hipLaunchKernelGGL(i8q_copy_xor_kernel, dim3((uint32_t)std::min<size_t>((nb / 4 + kBlock - 1) / kBlock, 1024)),
 		                   dim3(kBlock), 0, st, (const uint32_t*)d_queries, nb / 4, nb / 4, 0x80808080u,
 		                   h->d_q_split.as<uint32_t>());
@@ -958,7 +971,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			hipLaunchKernelGGL(gq->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 			                   dim3(kBlock), 0, st, d_queries, (uint32_t)m, (const float*)nullptr,
 			                   (int*)nullptr, h->d_qself);
-		HIP_TRY(h, h->d_sample.ensure(m * (size_t)chunks * 32 * sizeof(int)));
+		HIP_TRY(h, grow_ws(h, h->d_sample, m * (size_t)chunks * 32 * sizeof(int)));
 		GemmI8qParams sp{};
 		sp.base = h->d_base_i8q;
 		sp.bp = h->d_bp_i8q;
@@ -1178,7 +1191,7 @@ int sampled_pass_f16(expann_index* h, const GemmF16Variant* gvf, size_t m, size_
                      float* d_tau, uint32_t* d_tau_row, hipStream_t st, bool* done) {
 	*done = false;
 	auto ensure_sample = [&](size_t need) -> int {
-		HIP_TRY(h, h->d_sample.ensure(need));
+		HIP_TRY(h, grow_ws(h, h->d_sample, need));
 		return EXPANN_OK;
 	};
 	SampleTauParams tp{};
@@ -1502,7 +1515,7 @@ int SearchPass::prepare_queries(bool* restart) {
 		if (rc != EXPANN_OK)
 			return rc;
 		const size_t nv = m * (size_t)h->dim;
-		HIP_TRY(h, h->d_q_split.ensure(nv * 4));
+		HIP_TRY(h, grow_ws(h, h->d_q_split, nv * 4));
 		// scaled fp16 queries, ||q||^2, and the largest |q| (range check, read back at the end):
 		// one memset of the flag block, one kernel
 		// (latency mode, one workgroup: the kernel clears the flag block itself and, when the queries
@@ -1524,7 +1537,7 @@ int SearchPass::prepare_queries(bool* restart) {
 	}
 	if (gvb) {  // queries -> bf16 hi/lo planes
 		const size_t nv = m * (size_t)h->dim;
-		HIP_TRY(h, h->d_q_split.ensure(nv * 4));
+		HIP_TRY(h, grow_ws(h, h->d_q_split, nv * 4));
 		hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nv + kBlock - 1) / kBlock)),
 		                   dim3(kBlock), 0, st, (const float*)d_queries, m, h->dim,
 		                   h->d_q_split.as<__bf16>());
@@ -1912,7 +1925,7 @@ int search_pass(expann_index* h, const void* d_queries, size_t m, size_t k, uint
 	if (h->dtype == EXPANN_DTYPE_U8) {
 		// fp32 queries -> uint8 (trunc); values outside [0,255] are counted and rejected below
 		const size_t nv = m * (size_t)h->dim;
-		HIP_TRY(h, h->d_q8.ensure(nv));
+		HIP_TRY(h, grow_ws(h, h->d_q8, nv));
 		int rcw = ensure_workspace(h, m, 2048);
 		if (rcw != EXPANN_OK)
 			return rcw;
@@ -2383,9 +2396,20 @@ int expann_merge_topk_strided_device(int device, const uint64_t* d_in_ids, const
 		g_create_error = "hipSetDevice failed";
 		return EXPANN_ERR_HIP;
 	}
-	hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
-	                   dim3(kBlock), 0, (hipStream_t)stream, d_in_ids, d_in_dists, ids_stride,
-	                   dists_stride, (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids, d_out_dists);
+	if (m >= (1ull << 31) || n_lists * k >= (1ull << 31)) {
+		g_create_error = "expann_merge_topk_device: m or n_lists * k beyond 2^31";
+		return EXPANN_ERR_INVALID_ARG;
+	}
+	// one wave per query; the query's n_lists * k entries staged in LDS while they fit 48 KiB
+	const size_t lds = n_lists * k * 12;
+	if (lds <= (48u << 10))
+		hipLaunchKernelGGL(merge_topk_kernel<true>, dim3((uint32_t)m), dim3(kWave), lds, (hipStream_t)stream, d_in_ids,
+		                   d_in_dists, ids_stride, dists_stride, (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids,
+		                   d_out_dists);
+	else
+		hipLaunchKernelGGL(merge_topk_kernel<false>, dim3((uint32_t)m), dim3(kWave), 0, (hipStream_t)stream, d_in_ids,
+		                   d_in_dists, ids_stride, dists_stride, (uint32_t)n_lists, (uint32_t)m, (uint32_t)k, d_out_ids,
+		                   d_out_dists);
 	if (hipGetLastError() != hipSuccess) {
 		g_create_error = "merge_topk_kernel launch failed";
 		return EXPANN_ERR_HIP;
@@ -2411,6 +2435,8 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 	*n_kept = 0;
 	if (n_ids == 0)
 		return EXPANN_OK;
+	if (n_ids >= (1ull << 32))
+		return h->fail(EXPANN_ERR_INVALID_ARG, "more than 2^32 ids");
 	for (size_t i = 0; i < n_ids; ++i)
 		if (ids[i] < h->id_offset || ids[i] - h->id_offset >= h->n)
 			return h->fail(EXPANN_ERR_INVALID_ARG, "id out of range");
@@ -2461,19 +2487,26 @@ int expann_score_ids(expann_index* h, const void* query, const uint64_t* ids, si
 		                    (float*)d_sc};
 		hipLaunchKernelGGL(sv->fn, dim3(blocks), dim3(kBlock), 0, h->stream, sp);
 	}
+	// the `d < cutoff` filter, order kept (src/quantizer.h:42-46): compacted on the device, only the
+	// survivors and their count come back
+	DevBuf b_kid, b_ksc, b_cnt;
+	HIP_TRY(h, b_kid.alloc(sizeof(uint64_t) * n_ids));
+	HIP_TRY(h, b_ksc.alloc(sizeof(float) * n_ids));
+	HIP_TRY(h, b_cnt.alloc(sizeof(uint32_t)));
+	FilterScoresParams fp{(const uint64_t*)d_idl, (const float*)d_sc, (uint32_t)n_ids, cutoff, b_kid.as<uint64_t>(),
+	                      b_ksc.as<float>(), b_cnt.as<uint32_t>()};
+	hipLaunchKernelGGL(filter_scores_kernel, dim3(1), dim3(1024), 0, h->stream, fp);
 	HIP_TRY(h, hipGetLastError());
-	std::vector<float> sc(n_ids);
-	HIP_TRY(h, hipMemcpyAsync(sc.data(), d_sc, sizeof(float) * n_ids, hipMemcpyDeviceToHost, h->stream));
+	uint32_t kept = 0;
+	HIP_TRY(h, hipMemcpyAsync(&kept, b_cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	if (bad_host)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "query values outside [0,255] for the uint8 metric");
-	size_t kept = 0;
-	for (size_t i = 0; i < n_ids; ++i)  // src/quantizer.h:42-46: keep iff d < cutoff, order kept
-		if (sc[i] < cutoff) {
-			kept_ids[kept] = ids[i];
-			kept_scores[kept] = sc[i];
-			++kept;
-		}
+	if (kept) {
+		HIP_TRY(h, hipMemcpyAsync(kept_ids, b_kid.p, sizeof(uint64_t) * kept, hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(h, hipMemcpyAsync(kept_scores, b_ksc.p, sizeof(float) * kept, hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(h, hipStreamSynchronize(h->stream));
+	}
 	*n_kept = kept;
 	return EXPANN_OK;
 }

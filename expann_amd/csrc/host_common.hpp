@@ -60,7 +60,9 @@ template <typename T> struct PinPtr {
 	T** operator&() { return &p; }
 	explicit operator bool() const { return p != nullptr; }
 };
-// a DevPtr that only ever grows: ensure(n) keeps the allocation when it is large enough
+// a DevPtr that only ever grows: ensure(n) keeps the allocation when it is large enough.  Growing
+// frees the old block: work still in flight that reads it must have drained first (the callers with
+// deferred searches outstanding synchronise their stream before they grow a shared buffer).
 template <typename T> struct GrowPtr : DevPtr<T> {
 	size_t bytes = 0;
 	hipError_t ensure(size_t need) {

@@ -309,6 +309,7 @@ constexpr int kF16Threads = EXPANN_F16_THREADS;  // 256: two workgroups per CU; 
 constexpr int kF16WgPerCu = 512 / kF16Threads;
 constexpr int kF16Waves = kF16Threads / 64;
 constexpr int kF16TQ = 64 * kF16Waves;       // queries per workgroup
+static_assert(kF16Waves == 4 && kF16TQ == 256, "gather_logs_kernel files the logs of 4 waves x 64 queries per workgroup");
 constexpr int kF16TB = 64;                   // rows per tile (= per workgroup step)
 constexpr int kF16Prefetch = 2;              // tiles in flight ahead of the one being multiplied
 constexpr int kF16Bufs = kF16Prefetch + 1;   // LDS tile buffers

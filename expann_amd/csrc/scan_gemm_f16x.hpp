@@ -398,7 +398,8 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		c[6] = t1 - t0;
 		c[7] = wall0;
 	}
-	if (p.clk && tid == 0) {  // (debug 16: every workgroup's start / end on the 100 MHz clock, and its CU)
+	if (p.clk && tid == 0 && blockIdx.x < 65536) {  // (debug 16: every workgroup's start / end on the 100 MHz clock, and its CU;
+	                                                 // the host's buffer holds 65 536 records)
 		p.clk[18 + 3 * (size_t)blockIdx.x] = wall0;
 		p.clk[19 + 3 * (size_t)blockIdx.x] = wall_clock64();
 		uint32_t hwid;

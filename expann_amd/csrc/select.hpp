@@ -507,49 +507,86 @@ __global__ __launch_bounds__(1024) void max_f32_kernel(const float* in, size_t n
 	}
 }
 
-// k-way merge of n_lists ascending (score, id) lists per query; one thread per query.
-// Lists are padded with (+inf, UINT64_MAX).  Order: score, then id (64-bit).
-// List g starts at in_ids + g*ids_stride / in_dists + g*dists_stride (elements): m*k each for
-// separate [n_lists][m][k] arrays, or the chunk size when every rank's chunk is [ids | dists].
-__global__ __launch_bounds__(kBlock) void merge_topk_kernel(const uint64_t* in_ids,
-                                                            const float* in_dists,
+// k-way merge of n_lists ascending (score, id) lists per query: ONE WAVE per query, every element
+// finds its own place.  Lists are padded with (+inf, UINT64_MAX); order: score, then id (64-bit),
+// then list number (distinct shards never tie on an id).  List g starts at in_ids + g*ids_stride /
+// in_dists + g*dists_stride (elements): m*k each for separate [n_lists][m][k] arrays, the chunk size
+// when every rank's chunk is [ids | dists], or the slice stride of the all-to-all exchange.
+// Element i of list g has rank i + sum over the other lists of (entries ordered before it) -- a
+// binary search per list in the sorted lists, no serial k-step chain (round 2's one-thread-per-query
+// merge walked k x n_lists dependent global loads: latency-bound whatever m is, and its per-list
+// cursor array lived in scratch).  STAGE: the n_lists x k entries of the query are first copied to
+// LDS (12 B each) and searched there; else they are searched where they lie (lists too long for LDS).
+template <bool STAGE>
+__global__ __launch_bounds__(kWave) void merge_topk_kernel(const uint64_t* in_ids, const float* in_dists,
                                                             size_t ids_stride, size_t dists_stride,
-                                                            uint32_t n_lists, uint32_t m,
-                                                            uint32_t k, uint64_t* out_ids,
-                                                            float* out_dists) {
-	const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+                                                            uint32_t n_lists, uint32_t m, uint32_t k,
+                                                            uint64_t* out_ids, float* out_dists) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+	const uint32_t qi = blockIdx.x, lane = threadIdx.x;
 	if (qi >= m)
 		return;
-	constexpr int kMaxLists = 64;
-	uint32_t pos[kMaxLists];
-	for (uint32_t g = 0; g < n_lists; ++g)
-		pos[g] = 0;
-	for (uint32_t i = 0; i < k; ++i) {
-		uint32_t best = n_lists;
-		uint32_t bo = 0;
-		uint64_t bid = ~0ull;
-		for (uint32_t g = 0; g < n_lists; ++g) {
-			if (pos[g] >= k)
-				continue;
-			const size_t off = (size_t)qi * k + pos[g];
-			const uint64_t id = in_ids[g * ids_stride + off];
-			if (id == ~0ull)
-				continue;  // padding: this list is exhausted
-			const uint32_t o = float_to_ordered(in_dists[g * dists_stride + off]);
-			if (best == n_lists || o < bo || (o == bo && id < bid)) {
-				best = g;
-				bo = o;
-				bid = id;
-			}
-		}
-		if (best == n_lists) {
-			out_ids[(size_t)qi * k + i] = ~0ull;
-			out_dists[(size_t)qi * k + i] = __builtin_inff();
+	const uint32_t total = n_lists * k;
+	uint64_t* const s_id = reinterpret_cast<uint64_t*>(merge_smem);            // [total]
+	uint32_t* const s_sc = reinterpret_cast<uint32_t*>(merge_smem + 8 * (size_t)total);  // [total]
+	const size_t qoff = (size_t)qi * k;
+	auto load = [&](uint32_t g, uint32_t i, uint64_t& id, uint32_t& sc) {
+		if (STAGE) {
+			id = s_id[g * k + i];
+			sc = s_sc[g * k + i];
 		} else {
-			out_ids[(size_t)qi * k + i] = bid;
-			out_dists[(size_t)qi * k + i] = ordered_to_float(bo);
-			pos[best]++;
+			id = in_ids[g * ids_stride + qoff + i];
+			sc = id == ~0ull ? 0xFFFFFFFFu : float_to_ordered(in_dists[g * dists_stride + qoff + i]);
 		}
+	};
+	uint32_t n_valid = 0;
+	if (STAGE) {
+		for (uint32_t e = lane; e < total; e += kWave) {
+			const uint32_t g = e / k, i = e - g * k;
+			const uint64_t id = in_ids[g * ids_stride + qoff + i];
+			s_id[e] = id;
+			s_sc[e] = id == ~0ull ? 0xFFFFFFFFu : float_to_ordered(in_dists[g * dists_stride + qoff + i]);
+		}
+		__syncthreads();
+	}
+	for (uint32_t e = lane; e < total; e += kWave) {
+		const uint32_t g = e / k, i = e - g * k;
+		uint64_t id;
+		uint32_t sc;
+		load(g, i, id, sc);
+		if (id == ~0ull)
+			continue;  // padding: behind every real entry
+		n_valid++;
+		uint32_t rank = i;
+		for (uint32_t g2 = 0; g2 < n_lists && rank < k; ++g2) {
+			if (g2 == g)
+				continue;
+			// entries of list g2 ordered before (sc, id, g): none beyond position k - rank matter
+			uint32_t lo = 0, hi = k - rank;
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				uint64_t xid;
+				uint32_t xsc;
+				load(g2, mid, xid, xsc);
+				const bool before = xsc < sc || (xsc == sc && (xid < id || (xid == id && g2 < g)));
+				if (before)
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			rank += lo;
+		}
+		if (rank < k) {
+			out_ids[qoff + rank] = id;
+			out_dists[qoff + rank] = ordered_to_float(sc);
+		}
+	}
+	// fewer than k real entries in all lists together: pad the tail
+	for (int off = 32; off > 0; off >>= 1)
+		n_valid += __shfl_xor(n_valid, off);
+	for (uint32_t r = n_valid + lane; r < k; r += kWave) {
+		out_ids[qoff + r] = ~0ull;
+		out_dists[qoff + r] = __builtin_inff();
 	}
 }
 

@@ -177,7 +177,8 @@ class ShardedBruteForceEngine:
 
     def param_list(self):
         return {"devices": ",".join(map(str, self.devices)), "shards": str(self.shards()),
-                "exchange": {0: "none", 1: "rccl", 2: "device copies", 3: "caller"}[self.exchange()]}
+                "exchange": {0: "none", 1: "rccl", 2: "device copies", 3: "caller"}[self.exchange()],
+                "exchange_pattern": {0: "none", 1: "all-gather", 2: "all-to-all of query slices"}[self.exchange_pattern()]}
 
     def store_many_vectors(self, rows):
         rows = np.ascontiguousarray(rows, dtype=_NP_DTYPE[self.dtype])
@@ -215,8 +216,52 @@ class ShardedBruteForceEngine:
         self._check(self._L.expann_sharded_search_device(self._h, C.c_void_p(q_ptr), m, k, C.c_void_p(ids_ptr),
                                                          C.c_void_p(dists_ptr), C.c_void_p(stream)))
 
+    def search_devices(self, q_ptrs, m, k, ids_ptrs, dists_ptrs):
+        """expann_sharded_search_devices (in-process form, everything resident): q_ptrs[r] = the m queries
+        on shard r's device; shard r leaves its merged query slice (self.slice(m, r)) at ids_ptrs[r] /
+        dists_ptrs[r].  Deferred by default: sync() waits for every device and validates."""
+        n = len(q_ptrs)
+        arr = lambda ps: (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ps])
+        self._check(self._L.expann_sharded_search_devices(self._h, arr(q_ptrs), m, k, arr(ids_ptrs), arr(dists_ptrs)))
+
+    def slice(self, m, shard):
+        """[lo, hi): the queries shard `shard` merges (exchange pattern 2, search_devices)."""
+        lo, hi = C.c_size_t(), C.c_size_t()
+        self._check(self._L.expann_sharded_slice(self._h, m, int(shard), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     def sync(self):
         self._check(self._L.expann_sharded_sync(self._h))
+
+    def exchange_pattern(self):
+        """0 none, 1 all-gather of whole chunks, 2 all-to-all of query slices"""
+        return self._L.expann_sharded_exchange_pattern(self._h)
+
+    def comm_ranks(self):
+        """ranks of the RCCL communicator as ncclCommCount reports them (0: no communicator)"""
+        return self._L.expann_sharded_comm_ranks(self._h)
+
+    def last_enqueue_ms(self):
+        return self._L.expann_sharded_last_enqueue_ms(self._h)
+
+    def set_alltoallv_fn(self, fn):
+        """Rank form: fn(d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes, rank, world, stream)
+        -> 0 (lists of `world` ints; entry [rank] is 0 bytes) moves the query slices of exchange pattern 2
+        in place of RCCL's send / recv groups (expann_sharded_set_alltoallv_fn); None = RCCL again."""
+        if fn is None:
+            self._a2afn = _lib.ALLTOALLV_FN(0)
+        else:
+            def tramp(_ctx, d_send, so, sb, d_recv, ro, rb, rank, world, stream):
+                try:
+                    return int(fn(d_send or 0, [so[j] for j in range(world)], [sb[j] for j in range(world)],
+                                  d_recv or 0, [ro[j] for j in range(world)], [rb[j] for j in range(world)],
+                                  rank, world, stream or 0))
+                except Exception:  # (an exception cannot cross the C frames above this one)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._a2afn = _lib.ALLTOALLV_FN(tramp)  # (kept alive with the engine)
+        self._check(self._L.expann_sharded_set_alltoallv_fn(self._h, self._a2afn, None))
 
     def set_exchange_fn(self, fn):
         """Rank form: fn(d_send, d_recv, nbytes, rank, world, stream) -> 0 gathers every rank's chunk of

@@ -133,3 +133,79 @@ class GridShardedSearch:
         ids = torch.cat([v[0][:b - a] for v, (a, b) in zip(views, parts)], 0)
         dists = torch.cat([v[1][:b - a] for v, (a, b) in zip(views, parts)], 0)
         return ids, dists
+
+
+def slice_range(m, j, world):
+    """query slice j of exchange pattern 2 (csrc/expann_sharded.hip, expann_sharded_slice):
+    [min(m, j * ceil(m/G)), min(m, (j+1) * ceil(m/G)))"""
+    per = (m + world - 1) // world
+    return min(m, j * per), min(m, (j + 1) * per)
+
+
+class SliceShardedSearch:
+    """Pure row sharding with exchange pattern 2 through torch.distributed -- the Python mirror of what
+    expann_sharded_search_device does behind the C ABI: (1) every rank scans ITS rows for ALL queries;
+    (2) an all-to-all sends rank j the slice-j rows of every rank's [m][k] result (list g of my slice comes
+    from rank g); (3) every rank merges its slice -- m/G queries, G lists; (4) the merged slices are
+    all-gathered (ragged: the last slices may be short or empty), so every rank ends with the full result.
+    Per rank 2 (G-1)/G x 12 m k bytes arrive instead of the (G-1) x 12 m k of one all-gather of whole
+    chunks, and each rank merges m/G queries instead of m."""
+
+    def __init__(self, dist, world, rank, local_search, merge_slices, alloc):
+        """local_search(queries, k, chunk): this rank's rows, all queries, results (global ids) into the
+        uint8 chunk [ids m*k | dists m*k]; merge_slices(lists_ids[G*per, k], lists_d[G*per, k], n_lists,
+        per, cnt, k, out_ids[cnt, k], out_d[cnt, k]): list g starts at row g*per; alloc(name, nbytes, like)."""
+        self.dist, self.world, self.rank = dist, world, rank
+        self.local_search, self.merge_slices, self.alloc = local_search, merge_slices, alloc
+
+    def _exchange(self, pairs):
+        """pairs[j] = (tensor sent to rank j, tensor received from rank j); the own part is a copy"""
+        # (gloo moves host memory only: device tensors are staged through the host in stream order --
+        # the rehearsal on a one-GPU box; RCCL sends and receives device memory directly)
+        stage = self.dist.get_backend() == "gloo"
+        ops, landed = [], []
+        for j, (snd, rcv) in enumerate(pairs):
+            if j == self.rank:
+                if rcv.numel():
+                    rcv.copy_(snd)
+                continue
+            if snd.numel():
+                ops.append(self.dist.P2POp(self.dist.isend, snd.cpu() if stage and snd.is_cuda else snd.contiguous(), j))
+            if rcv.numel():
+                if stage and rcv.is_cuda:
+                    import torch
+                    host = torch.empty(rcv.shape, dtype=rcv.dtype)
+                    landed.append((rcv, host))
+                    ops.append(self.dist.P2POp(self.dist.irecv, host, j))
+                else:
+                    ops.append(self.dist.P2POp(self.dist.irecv, rcv, j))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for rcv, host in landed:
+            rcv.copy_(host)
+
+    def search(self, queries, k):
+        m, G, r = queries.shape[0], self.world, self.rank
+        mine = self.alloc("mine", chunk_bytes(m, k), queries)
+        self.local_search(queries, k, mine)
+        ids, dists = unpack_chunk(mine, m, k)
+        if G == 1:
+            return ids, dists
+        per = (m + G - 1) // G
+        lo, hi = slice_range(m, r, G)
+        cnt = hi - lo
+        lists = self.alloc("lists", chunk_bytes(G * per, k), queries)
+        l_ids, l_d = unpack_chunk(lists, G * per, k)
+        rng = [slice_range(m, j, G) for j in range(G)]
+        for src, dst in ((ids, l_ids), (dists, l_d)):
+            self._exchange([(src[a:b], dst[j * per:j * per + cnt]) for j, (a, b) in enumerate(rng)])
+        merged = self.alloc("merged", chunk_bytes(per, k), queries)
+        m_ids, m_d = unpack_chunk(merged, per, k)
+        if cnt:
+            self.merge_slices(l_ids, l_d, G, per, cnt, k, m_ids[:cnt], m_d[:cnt])
+        full = self.alloc("full", chunk_bytes(m, k), queries)
+        f_ids, f_d = unpack_chunk(full, m, k)
+        for src, dst in ((m_ids, f_ids), (m_d, f_d)):
+            self._exchange([(src[:cnt], dst[a:b]) for (a, b) in rng])
+        return f_ids, f_d

@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define EXPANN_ABI_VERSION 1
+/* 2: expann_profile grew (deferred_searches); expann_sharded_* gained the device-resident in-process
+ * search, the all-to-all exchange pattern and its caller-transport hook */
+#define EXPANN_ABI_VERSION 2
 
 enum expann_status {
 	EXPANN_OK = 0,
@@ -129,22 +131,26 @@ int expann_merge_topk_strided_device(int device, const uint64_t* d_in_ids, const
 /* row-sharded brute force over the GPUs of one node (SURVEY 8b "create(..., devices, n_dev, ...)",
  * 8e; csrc/expann_sharded.hip) -------------------------------------------------------------------
  * Shard r holds the contiguous rows [r * ceil(N/G), min(N, (r+1) * ceil(N/G))) and searches ALL
- * queries on its own device; the fixed-size per-shard results [m][k] of (score, global id) are
- * exchanged with ONE ncclAllGather (RCCL over xGMI) and merged in the reference's (score, id) order,
- * so ids and distances are bit-identical to the single-device index (contiguous ranges + global
- * ids).  The reference has no counterpart (one engine, one thread: src/basic_bench.h:83-84); the
- * calls mirror the single-device ones above (engine construction src/bench_runner.h:33,
- * store_vector / build / query_k src/ann_engine.h:23-29). */
+ * queries on its own device; the per-shard results [m][k] of (score, global id) are exchanged over
+ * RCCL (xGMI) and merged in the reference's (score, id) order, so ids and distances are bit-identical
+ * to the single-device index (contiguous ranges + global ids).  Two exchange patterns (option
+ * "exchange_pattern"): 2 (default) = an all-to-all of QUERY SLICES -- rank j receives, from every
+ * shard, the results of the queries [j * ceil(m/G), ...) and merges those (m/G queries, G lists);
+ * the rank form then all-gathers the merged slices; 1 = ONE ncclAllGather of every shard's whole
+ * [ids m*k u64 | dists m*k f32] chunk, every rank merges all m queries.  The reference has no
+ * counterpart (one engine, one thread: src/basic_bench.h:83-84); the calls mirror the
+ * single-device ones above (engine construction src/bench_runner.h:33, store_vector / build /
+ * query_k src/ann_engine.h:23-29). */
 typedef struct expann_sharded expann_sharded;
-/* In-process form: ONE handle drives n_dev devices of this node (one stream per device,
- * ncclCommInitAll at build).  devices[] may name a device more than once (several shards on one
- * GPU; the exchange then runs as device copies, RCCL refuses duplicate devices). */
+/* In-process form: ONE handle drives n_dev devices of this node (one stream and one enqueue thread
+ * per device, ncclCommInitAll at build).  devices[] may name a device more than once (several shards
+ * on one GPU; the exchange then runs as device copies, RCCL refuses duplicate devices). */
 int expann_sharded_create(int dim, int dtype, int metric, const int* devices, int n_dev,
                           expann_sharded** out);
 /* One-process-per-GPU form: rank `rank` of `world` ranks on `device`; id128 = the 128 bytes rank 0
  * got from expann_sharded_unique_id (ncclGetUniqueId), distributed by the launcher.  Collective:
  * every rank calls it (ncclCommInitRank).  id128 == NULL: no RCCL communicator -- one rank needs
- * none, more ranks exchange through expann_sharded_set_exchange_fn. */
+ * none, more ranks exchange through expann_sharded_set_exchange_fn / _set_alltoallv_fn. */
 int expann_sharded_unique_id(void* id128);
 int expann_sharded_create_rank(int dim, int dtype, int metric, int device, int rank, int world,
                                const void* id128, expann_sharded** out);
@@ -155,34 +161,63 @@ const char* expann_sharded_last_error(const expann_sharded* h);
 int expann_sharded_add(expann_sharded* h, const void* rows, size_t n);
 int expann_sharded_build(expann_sharded* h);
 /* Adopt rows already in the shard's device memory (as expann_set_base_device): the rank form's
- * only way to receive rows (shard = 0, id_offset = global number of the rank's first row);
+ * only way to receive rows (shard = 0, id_offset = global number of the rank's first row; n = 0
+ * with d_rows = NULL declares the rank's range empty -- the ceil partition leaves trailing ranks
+ * without rows when N < G * (G-1) -- and the rank still takes part in every exchange);
  * in-process form: shards in order 0, 1, ... instead of add + build. */
 int expann_sharded_set_shard_device(expann_sharded* h, int shard, const void* d_rows, size_t n,
                                     uint64_t id_offset);
 size_t expann_sharded_size(const expann_sharded* h);  /* rows over all local shards */
 int expann_sharded_shards(const expann_sharded* h);   /* shards in use (rank form: world) */
-int expann_sharded_exchange(const expann_sharded* h); /* 0 none (one shard), 1 RCCL, 2 device copies,
-                                                         3 the caller's function */
-/* Rank form: the all-gather of the per-rank result chunks through the caller's transport instead
- * of RCCL (another fabric; ranks that share one GPU, which RCCL refuses; tests).  fn gathers
- * `bytes` bytes of device memory d_send from every rank into d_recv (rank r's chunk at r * bytes)
- * ordered after the work already on `stream` and complete, as far as `stream` is concerned, when it
- * returns or in stream order; 0 = ok.  fn == NULL goes back to the communicator. */
+int expann_sharded_exchange(const expann_sharded* h); /* transport: 0 none (one shard), 1 RCCL, 2 device
+                                                         copies, 3 the caller's function */
+int expann_sharded_exchange_pattern(const expann_sharded* h); /* 0 none, 1 all-gather of chunks, 2 all-to-all
+                                                                 of query slices */
+/* ranks of the RCCL communicator as RCCL reports them (ncclCommCount); 0 = no communicator */
+int expann_sharded_comm_ranks(const expann_sharded* h);
+/* host time the last in-process search spent enqueuing (scan + exchange + merge of all shards, up to
+ * the point where the host starts waiting), milliseconds */
+double expann_sharded_last_enqueue_ms(const expann_sharded* h);
+/* Rank form: the exchange through the caller's transport instead of RCCL (another fabric; ranks
+ * that share one GPU, which RCCL refuses; tests).  expann_exchange_fn (pattern 1) gathers `bytes`
+ * bytes of device memory d_send from every rank into d_recv (rank r's chunk at r * bytes);
+ * expann_alltoallv_fn (pattern 2) sends send_bytes[j] bytes at d_send + send_off[j] to rank j and
+ * receives recv_bytes[j] bytes from rank j at d_recv + recv_off[j] (arrays of `world` entries; entry
+ * [rank] is always 0 bytes: the library copies what stays).  Both: ordered after the work already
+ * on `stream`, complete -- as far as `stream` is concerned -- on return or in stream order; 0 = ok.
+ * NULL goes back to the communicator.  With both set, "exchange_pattern" chooses. */
 typedef int (*expann_exchange_fn)(void* ctx, const void* d_send, void* d_recv, size_t bytes, int rank,
                                   int world, void* stream);
+typedef int (*expann_alltoallv_fn)(void* ctx, const void* d_send, const size_t* send_off,
+                                   const size_t* send_bytes, void* d_recv, const size_t* recv_off,
+                                   const size_t* recv_bytes, int rank, int world, void* stream);
 int expann_sharded_set_exchange_fn(expann_sharded* h, expann_exchange_fn fn, void* ctx);
+int expann_sharded_set_alltoallv_fn(expann_sharded* h, expann_alltoallv_fn fn, void* ctx);
 /* in-process form, host buffers: as expann_search. */
 int expann_sharded_search(expann_sharded* h, const void* queries, size_t m, size_t k, uint64_t* ids,
                           float* dists);
-/* rank form, device buffers on `stream` (NULL = the handle's own): local search, ncclAllGather,
- * merge; every rank ends with the full ids[m][k] / dists[m][k].  Collective.  With the option
+/* in-process form, everything resident: d_queries[r] = the m queries in the memory of shard r's
+ * device; shard r merges the query slice expann_sharded_slice(h, m, r, &lo, &hi) and leaves it in
+ * d_ids[r][(hi-lo)][k] / d_dists[r] on its device (ordered on the shard's own stream).  With
+ * "async_search" = 1 (default) the call returns once everything is enqueued on every device;
+ * expann_sharded_sync waits for all shards and validates the searches since the last sync
+ * (EXPANN_ERR_OVERFLOW: repeat them with "async_search" = 0). */
+int expann_sharded_search_devices(expann_sharded* h, const void* const* d_queries, size_t m, size_t k,
+                                  uint64_t* const* d_ids, float* const* d_dists);
+/* query slice [*q_lo, *q_hi) that shard (rank) `shard` merges under pattern 2 and in
+ * expann_sharded_search_devices: [min(m, shard * ceil(m/G)), min(m, (shard+1) * ceil(m/G))) */
+int expann_sharded_slice(const expann_sharded* h, size_t m, int shard, size_t* q_lo, size_t* q_hi);
+/* rank form, device buffers on `stream` (NULL = the handle's own): local search, exchange, merge;
+ * every rank ends with the full ids[m][k] / dists[m][k].  Collective.  With the option
  * "async_search" = 1 the call returns without a host wait (expann_sharded_sync, as expann_sync). */
 int expann_sharded_search_device(expann_sharded* h, const void* d_queries, size_t m, size_t k,
                                  uint64_t* d_ids, float* d_dists, void* stream);
 int expann_sharded_sync(expann_sharded* h);
-/* "exchange" (in-process form: 0 auto, 1 RCCL, 2 device copies), "async_search" (in-process form:
- * 1 (default) = the shards' searches are enqueued on all devices before the host waits for any);
- * every other option goes to the shards' indexes (expann_set_option). */
+/* "exchange" (in-process form, transport: 0 auto, 1 RCCL, 2 device copies), "exchange_pattern" (0 auto
+ * = 2, 1 all-gather of whole chunks, 2 all-to-all of query slices), "threads" (in-process form: 1
+ * (default) = one enqueue thread per shard, 0 = the calling thread enqueues every device in turn),
+ * "async_search" (in-process form: 1 (default) = the shards' searches are enqueued on all devices
+ * before the host waits for any); every other option goes to the shards' indexes (expann_set_option). */
 int expann_sharded_set_option(expann_sharded* h, const char* name, long value);
 
 /* batched candidate scoring (quantized_scorer::filter_by_score, src/quantizer.h:20-59):

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.expann_abi_version() == 1
+    assert lib.expann_abi_version() == 2
 
 
 def test_argument_validation_without_touching_a_gpu(lib):

@@ -23,8 +23,12 @@ def _same(a, b):
     return np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("n_dev,exchange,want", [(1, 0, 0), (1, 1, 1), (8, 0, 2), (3, 2, 2)])
-def test_inprocess_shards_equal_the_plain_index(oracle, n_dev, exchange, want):
+@pytest.mark.parametrize("n_dev,exchange,want,pattern,threads",
+                         [(1, 0, 0, 0, 1), (1, 1, 1, 0, 1), (1, 1, 1, 1, 1), (8, 0, 2, 0, 1), (8, 0, 2, 1, 1),
+                          (3, 2, 2, 2, 1), (3, 2, 2, 1, 0), (5, 0, 2, 2, 0)])
+def test_inprocess_shards_equal_the_plain_index(oracle, n_dev, exchange, want, pattern, threads):
+    """pattern 0 = the default (2: all-to-all of query slices), 1 = one all-gather of whole chunks;
+    threads 1 = one enqueue thread per shard (default), 0 = the calling thread enqueues all shards."""
     from expann_amd import ShardedBruteForceEngine
     rng = np.random.RandomState(5 + n_dev)
     n, d, m, k = 150_001, 128, 700, 10
@@ -35,10 +39,15 @@ def test_inprocess_shards_equal_the_plain_index(oracle, n_dev, exchange, want):
     eng = ShardedBruteForceEngine(d, "l2", "f32", devices=[0] * n_dev)
     if exchange:
         eng.set_option("exchange", exchange)
+    if pattern:
+        eng.set_option("exchange_pattern", pattern)
+    eng.set_option("threads", threads)
     eng.store_many_vectors(base[:40_000])
     eng.store_many_vectors(base[40_000:])
     eng.build()
     assert eng.size() == n and eng.shards() == n_dev and eng.exchange() == want
+    assert eng.exchange_pattern() == (0 if n_dev == 1 else (pattern or 2))
+    assert eng.comm_ranks() == (1 if want == 1 else 0)      # ncclCommCount of the one-rank communicator
     got = eng.query_k_batch(q, k)
     assert _same(got, _plain(base, q, k))
     ref = oracle.brute_force(base, q[:64], k, oracle.METRIC_L2_F32, n_threads=8)
@@ -155,3 +164,184 @@ def test_c3_shape_per_gpu_k100(oracle):
     assert np.array_equal(sids, ids.cpu().numpy().view(np.uint64)[:2000])
     assert np.array_equal(sd.view(np.uint32), dd.cpu().numpy()[:2000].view(np.uint32))
     sh.close()
+
+
+@pytest.mark.parametrize("n_dev,pattern,m,k", [(4, 2, 1000, 10), (4, 1, 1000, 10), (8, 2, 333, 100), (3, 2, 2, 10)])
+def test_inprocess_resident_search(oracle, n_dev, pattern, m, k):
+    """expann_sharded_search_devices: rows, queries and results all stay in device memory; shard r leaves
+    its merged query slice on its device; deferred by default (several searches back to back, one sync).
+    m = 2 over 3 shards: the last slice is empty."""
+    torch = pytest.importorskip("torch")
+    from expann_amd import ShardedBruteForceEngine
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    n, d = 200_003, 128
+    base = torch.randn(n, d, device="cuda", generator=g)
+    q = torch.randn(m, d, device="cuda", generator=g)
+    eng = ShardedBruteForceEngine(d, "l2", "f32", devices=[0] * n_dev)
+    eng.set_option("exchange_pattern", pattern)
+    per = (n + n_dev - 1) // n_dev
+    for r in range(n_dev):
+        lo, hi = r * per, min(n, (r + 1) * per)
+        eng.set_shard_device(r, base[lo:hi].data_ptr(), hi - lo, lo)
+    outs = []
+    for r in range(n_dev):
+        lo, hi = eng.slice(m, r)
+        outs.append((torch.empty(max(1, hi - lo), k, dtype=torch.int64, device="cuda"),
+                     torch.empty(max(1, hi - lo), k, dtype=torch.float32, device="cuda")))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        eng.search_devices([q.data_ptr()] * n_dev, m, k, [o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs])
+    eng.sync()
+    torch.cuda.synchronize()
+    assert eng.last_enqueue_ms() > 0
+    parts = [eng.slice(m, r) for r in range(n_dev)]
+    assert parts[0][0] == 0 and parts[-1][1] == m
+    ids = torch.cat([outs[r][0][:hi - lo] for r, (lo, hi) in enumerate(parts)], 0).cpu().numpy().view(np.uint64)
+    dd = torch.cat([outs[r][1][:hi - lo] for r, (lo, hi) in enumerate(parts)], 0).cpu().numpy()
+    sel = np.arange(0, m, max(1, m // 40))
+    rids, rd = oracle.brute_force(base.cpu().numpy(), q.cpu().numpy()[sel], k, oracle.METRIC_L2_F32, n_threads=16)
+    assert np.array_equal(ids[sel], rids) and np.array_equal(dd[sel].view(np.uint32), rd.view(np.uint32))
+    plain = _plain(base.cpu().numpy(), q.cpu().numpy(), k)
+    assert _same((ids, dd), plain)
+    eng.close()
+
+
+def test_enqueue_threads_keep_host_time_flat():
+    """The in-process form's host cost per search: one enqueue thread per shard against the calling thread
+    enqueuing shard after shard (8 shards on this box's one device, C2's per-GPU shape at G = 8: 125 k rows x
+    10 k queries).  The serial form's host time grows with the shard count; the threads' must not -- on one
+    device they still share the runtime's per-device locks, so the bound is loose and the numbers are printed
+    for DESIGN.md (on 8 devices nothing is shared)."""
+    torch = pytest.importorskip("torch")
+    import os
+    from expann_amd import ShardedBruteForceEngine
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    d, m, k, per = 128, 10_000, 10, 125_000
+    q = torch.randn(m, d, device="cuda", generator=g)
+    res = {}
+    for n_dev in (1, 8):
+        base = torch.randn(per * n_dev, d, device="cuda", generator=g)
+        for threads in (1, 0):
+            eng = ShardedBruteForceEngine(d, "l2", "f32", devices=[0] * n_dev)
+            eng.set_option("threads", threads)
+            for r in range(n_dev):
+                eng.set_shard_device(r, base[r * per:(r + 1) * per].data_ptr(), per, r * per)
+            outs = [(torch.empty(max(1, eng.slice(m, r)[1] - eng.slice(m, r)[0]), k, dtype=torch.int64, device="cuda"),
+                     torch.empty(max(1, eng.slice(m, r)[1] - eng.slice(m, r)[0]), k, dtype=torch.float32, device="cuda"))
+                    for r in range(n_dev)]
+            args = ([q.data_ptr()] * n_dev, m, k, [o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs])
+            for _ in range(3):
+                eng.search_devices(*args)
+            eng.sync()
+            t = []
+            for _ in range(10):
+                eng.search_devices(*args)
+                t.append(eng.last_enqueue_ms())
+            eng.sync()
+            res[(n_dev, threads)] = sorted(t)[len(t) // 2]
+            eng.close()
+        del base
+    line = ("host enqueue ms per search (median of 10): 1 shard %.3f; 8 shards on one device: threads %.3f, "
+            "calling thread only %.3f" % (res[(1, 1)], res[(8, 1)], res[(8, 0)]))
+    print(line)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/enqueue_threads.txt", "w") as f:
+        f.write(line + "\n")
+    assert res[(8, 1)] <= res[(8, 0)] * 1.25, line
+
+
+def _thread_alltoallv(world):
+    """an expann_alltoallv_fn / expann_exchange_fn pair for `world` ranks living in ONE process (a thread
+    each): every rank posts its send buffer, a barrier, every rank pulls what is meant for it."""
+    import threading
+    import torch
+    bar = threading.Barrier(world)
+    posted = [None] * world
+
+    class Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def view(ptr, n):
+        return torch.as_tensor(Dev(ptr, n), device="cuda")
+
+    def a2a(d_send, so, sb, d_recv, ro, rb, rank, w, stream):
+        torch.cuda.ExternalStream(stream).synchronize()
+        posted[rank] = (d_send, so, sb)
+        bar.wait()
+        for j in range(w):
+            if rb[j]:
+                src, s_off, s_bytes = posted[j]
+                assert s_bytes[rank] == rb[j]
+                view(d_recv + ro[j], rb[j]).copy_(view(src + s_off[rank], rb[j]))
+        torch.cuda.synchronize()
+        bar.wait()
+        return 0
+
+    def gather(d_send, d_recv, nbytes, rank, w, stream):
+        torch.cuda.ExternalStream(stream).synchronize()
+        posted[rank] = d_send
+        bar.wait()
+        for j in range(w):
+            view(d_recv + j * nbytes, nbytes).copy_(view(posted[j], nbytes))
+        torch.cuda.synchronize()
+        bar.wait()
+        return 0
+    return a2a, gather
+
+
+@pytest.mark.parametrize("world,n,m,k,pattern", [(3, 150_001, 500, 10, 2), (3, 150_001, 500, 10, 1), (4, 6, 9, 4, 2),
+                                                 (4, 6, 9, 4, 1), (5, 90_000, 3, 100, 2)])
+def test_rank_form_protocol_with_a_rank_per_thread(oracle, world, n, m, k, pattern):
+    """The rank form of the C ABI (expann_sharded_create_rank without an RCCL id, _search_device) with the
+    exchange handed in by the caller, `world` ranks as threads of this process on the one GPU: scan ->
+    all-to-all of query slices -> merge of the own slice -> all-gather of the merged slices (pattern 2), or
+    one all-gather of whole chunks (pattern 1); every rank must end with the full result.  n = 6 over 4
+    ranks: the ceil partition gives 2, 2, 2, 0 rows -- the last rank holds none and still takes part;
+    m = 3 < world: empty query slices."""
+    torch = pytest.importorskip("torch")
+    import threading
+    from expann_amd import ShardedBruteForceEngine
+    d = 64
+    rng = np.random.RandomState(21)
+    base_h = rng.standard_normal((n, d)).astype(np.float32)
+    q_h = rng.standard_normal((m, d)).astype(np.float32)
+    base = torch.from_numpy(base_h).cuda()
+    q = torch.from_numpy(q_h).cuda()
+    a2a, gather = _thread_alltoallv(world)
+    per = (n + world - 1) // world
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            eng = ShardedBruteForceEngine(d, "l2", "f32", device=0, rank=r, world=world)
+            eng.set_alltoallv_fn(a2a)
+            eng.set_exchange_fn(gather)
+            eng.set_option("exchange_pattern", pattern)
+            lo, hi = min(n, r * per), min(n, (r + 1) * per)
+            eng.set_shard_device(0, base[lo:hi].data_ptr() if hi > lo else 0, hi - lo, lo)
+            assert eng.exchange() == 3 and eng.exchange_pattern() == pattern and eng.comm_ranks() == 0
+            ids = torch.empty(m, k, dtype=torch.int64, device="cuda")
+            dd = torch.empty(m, k, dtype=torch.float32, device="cuda")
+            st = torch.cuda.Stream()
+            for _ in range(2):
+                eng.search_device(q.data_ptr(), m, k, ids.data_ptr(), dd.data_ptr(), st.cuda_stream)
+            eng.sync()
+            st.synchronize()
+            res[r] = (ids.cpu().numpy().view(np.uint64), dd.cpu().numpy())
+            eng.close()
+        except Exception as e:       # (a failed rank would leave the others at the barrier)
+            errs.append((r, repr(e)))
+            raise
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errs, errs
+    ref = oracle.brute_force(base_h, q_h, k, oracle.METRIC_L2_F32, n_threads=8)
+    for r in range(world):
+        assert res[r] is not None and _same(res[r], ref), r

@@ -183,3 +183,97 @@ def test_shard_ranges_partition_the_base():
             edges = [shard_range(n, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def _slice_worker(rank, world, port, n, d, m, k, out):
+    """exchange pattern 2 (all-to-all of query slices + all-gather of the merged slices) over gloo, CPU
+    stand-ins for the scan and the merge; the ceil partition of the ROWS as the C ABI cuts them (trailing
+    ranks may hold no rows and then contribute all-padding lists)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import oracle_ctypes as oc
+    from expann_amd.sharded import SliceShardedSearch, ceil_shard_range, slice_range, unpack_chunk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(79)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    if n > 3:
+        base[n // 3] = base[2 * n // 3]          # a cross-shard exact tie
+    queries = rng.standard_normal((m, d)).astype(np.float32)
+    queries[0] = base[n // 3]
+    lo, hi = ceil_shard_range(n, rank, world)
+    bufs = {}
+
+    def alloc(name, nbytes, like):
+        if name not in bufs:
+            bufs[name] = torch.zeros(nbytes, dtype=torch.uint8)
+        return bufs[name]
+
+    def local_search(q, kk, chunk):
+        ids_v, d_v = unpack_chunk(chunk, q.shape[0], kk)
+        ids_v.fill_(-1)
+        d_v.fill_(float("inf"))
+        if hi > lo:
+            i, x = oc.brute_force(base[lo:hi], q.numpy(), kk)
+            i = np.where(i == np.uint64(2 ** 64 - 1), i, i + np.uint64(lo))
+            ids_v.copy_(torch.from_numpy(i.view(np.int64)))
+            d_v.copy_(torch.from_numpy(x))
+
+    def merge_slices(l_ids, l_d, n_lists, per, cnt, kk, o_ids, o_d):
+        all_ids = np.stack([l_ids[g * per:g * per + cnt].numpy() for g in range(n_lists)], 0)
+        all_d = np.stack([l_d[g * per:g * per + cnt].numpy() for g in range(n_lists)], 0)
+        i, dd = _merge_np(all_ids, all_d)
+        o_ids.copy_(torch.from_numpy(i))
+        o_d.copy_(torch.from_numpy(dd))
+
+    ss = SliceShardedSearch(dist, world, rank, local_search, merge_slices, alloc)
+    ids, dd = ss.search(torch.from_numpy(queries), k)
+    ref_ids, ref_d = oc.brute_force(base, queries, k)
+    ok = ids.shape[0] == m and np.array_equal(ids.numpy().view(np.uint64), ref_ids) and \
+        np.array_equal(dd.numpy(), ref_d)
+    # the slices partition the queries
+    edges = [slice_range(m, j, world) for j in range(world)]
+    ok = ok and edges[0][0] == 0 and edges[-1][1] == m and all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,m,k", [(2, 2003, 7, 10), (3, 2003, 10, 10), (4, 2003, 9, 100), (8, 2003, 12, 10),
+                                         (4, 5, 6, 3), (8, 2003, 5, 10)])
+def test_slice_exchange_matches_unsharded(world, n, m, k):
+    """pattern 2 of csrc/expann_sharded.hip, restated over gloo: ragged query slices, more ranks than
+    queries (empty slices), a rank without rows (n = 5 over 4 ranks: 2, 2, 1, 0), k = 100 > rows of a shard."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slice_worker, args=(r, world, port, n, 64, m, k, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(out.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` without a launcher drives 2 devices in one process (the in-process handle)
+    or fails loudly -- on this GPU-less box it must fail, never fall through to one GPU; so must a launcher
+    whose WORLD_SIZE disagrees with --gpus."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EXPANN_BENCH_REHEARSAL")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    if res.returncode == 0:
+        pytest.skip("a GPU box with >= 2 devices ran it")
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "--gpus 2" in res.stderr and ("HIP device" in res.stderr)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in res.stderr and res.stdout.strip() == ""
