@@ -425,9 +425,9 @@ struct GemmF16Variant {
 	 F16kGeom<D>::THREADS, 1, F16kGeom<D>::LDS_BYTES}
 const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(512),
                                    F16K_V(768), F16K_V(832), F16K_V(960)};
-// the 16x16x32 form of the full scan (scan_gemm_f16x.hpp); its sampled pass is the 32x32x16 kernel's
+// the 16x16x32 form of the full scan and of the sampled pass (scan_gemm_f16x.hpp)
 #define F16X_V(D)                                                                                  \
-	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,           \
+	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16x_kernel<D, true>, sqnorm_kernel<D>,          \
 	 f16_query_prep_kernel<D>, "scan_gemm_f16x<" #D ", false>", kF16TB, kF16TQ, kF16Threads,         \
 	 f16x_wg_per_cu<D>(), gemm_f16x_lds_bytes<D>(), 1}
 // (d = 64 with two workgroups per CU measured slower than scan_gemm_f16_kernel<64>'s three: 6.55 M vs
@@ -642,13 +642,18 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 }
 
 // one wave per query for lists of <= 512 keys, then (when the buffers allow longer lists) for
-// <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
+// <= 1024 and <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
 void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st) {
 	sel.wave_done = 0;
 	hipLaunchKernelGGL((select_wave_kernel<8, 4>), dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, sel,
 	                   (uint32_t)m);
 	sel.wave_done = 512;
 	if (cap > 512) {
+		// (k = 100: ~920-entry lists -- half the registers and ballots of the 2048-key form)
+		hipLaunchKernelGGL((select_wave_kernel<16, 2>), dim3((uint32_t)((m + 1) / 2)), dim3(128), 0, st, sel, (uint32_t)m);
+		sel.wave_done = 1024;
+	}
+	if (cap > 1024) {
 		hipLaunchKernelGGL((select_wave_kernel<32, 1>), dim3((uint32_t)m), dim3(64), 0, st, sel, (uint32_t)m);
 		sel.wave_done = 2048;
 	}

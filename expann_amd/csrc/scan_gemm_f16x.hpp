@@ -18,6 +18,8 @@
 // base rows from LDS (lane l: row l & 15 of tile column tc, same chunk), C: lane l, register r =
 // query 4 (l >> 4) + r of tile tq against row l & 15 of column tc.
 #pragma once
+#include <type_traits>
+
 #include "scan_gemm_f16.hpp"
 
 namespace expann {
@@ -67,6 +69,9 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	}
 	const uint32_t wg_q0 = qtile * WGQ;
 	const uint32_t q0 = wg_q0 + wave * 64;
+	// 16-query tiles of this wave that hold real queries (4 everywhere but in the batch's last query
+	// tile: m = 10 000 leaves 16 queries for it, i.e. one tile of wave 0 and none of waves 1-3)
+	const int n_tq = __builtin_amdgcn_readfirstlane(q0 >= p.m ? 0 : (int)((p.m - q0 + 15) / 16 < 4 ? (p.m - q0 + 15) / 16 : 4));
 
 	uint32_t t0 = chunk * p.tiles_per_block;
 	uint32_t t1 = t0 + p.tiles_per_block;
@@ -78,8 +83,13 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		t1 = p.n_tiles_sel;
 	uint32_t* const my_log_cnt = p.log_cnt + (size_t)blockIdx.x * WAVES + wave;
 	if (t0 >= t1) {
-		if (lane == 0)
+		if (SAMPLE) {  // (the host plans no empty chunk; if one appears its class maxima are "no row")
+			for (uint32_t i = lane; i < 64 * 32; i += 64)
+				if (q0 + (i >> 5) < p.m)
+					p.sample_out[((size_t)(q0 + (i >> 5)) * p.n_chunks + chunk) * 32 + (i & 31)] = -__builtin_inff();
+		} else if (lane == 0) {
 			*my_log_cnt = 0;
+		}
 		return;
 	}
 	const unsigned long long clk0 = p.clk ? clock64() : 0, wall0 = p.clk ? wall_clock64() : 0;
@@ -244,7 +254,18 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	//     plain vmcnt(0): the only loads outstanding are tile t+1's, issued a whole step earlier;
 	//   * a wave parked at the barrier leaves the matrix pipe to the other workgroup's wave on its
 	//     SIMD, which is in the middle of an MFMA stream of its own, not at a step boundary.
-	static_assert(!SAMPLE, "the sampled pass uses scan_gemm_f16_kernel<D, true>");
+	// SAMPLE (the threshold pass, 4.6 of DESIGN.md): the same stream without thresholds and candidate
+	// path.  A lane's accumulators of one tile column belong to ONE row, so the row term enters as the
+	// MFMA's C operand -- acc starts at -bn' -- and the epilogue is the running maximum of g = q16.b16 -
+	// bn' per (query register, row class): class = row mod 32 = 16 (tc & 1) + lane & 15, the columns of
+	// equal parity folded by one v_max3 (32 per step instead of the 32 x 32 form's subtract + max per
+	// accumulator).  A padding row's bn' is NaN: its g is NaN and never wins a max.
+	f32x4 smax[2][4];
+#pragma unroll
+	for (int par = 0; par < 2; ++par)
+#pragma unroll
+		for (int tq = 0; tq < 4; ++tq)
+			smax[par][tq] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 	stage(t0, 0);
 	stage(t0 + 1, 1);
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles t0, t0+1 landed, thq visible
@@ -279,19 +300,61 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		m2 = max3f(m2, m3, m4);
 		return __builtin_fmaxf(m0, m2);
 	};
+	// The step loop, compiled twice: FULL (every 16-query tile of the wave holds queries: the stream
+	// below is one basic block per step) and PARTIAL (the batch's last query tile: the MFMAs -- and, for
+	// a wave without any query, the fragment reads -- of the empty tiles are skipped behind wave-uniform
+	// branches; their accumulators stay at theta' = -inf, so the max tree and the candidate path need no
+	// change; staging and barriers are the same in both, the waves of a workgroup may take either).
+	auto run = [&](auto partial_tag) __attribute__((always_inline)) {
+	constexpr bool PARTIAL = decltype(partial_tag)::value;
+	float bnv[4];
+	auto fold = [&](int par) {  // SAMPLE: class maxima of the two columns of this parity
+#pragma unroll
+		for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				smax[par][tq][r] = max3f(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
+	};
 	auto mfma_col = [&](int tc, const f16x8 (&f)[KS]) {
+		if (SAMPLE) {
+			const float nb = -bnv[tc];
+			const f32x4 c0 = {nb, nb, nb, nb};
 #pragma unroll
-		for (int s = 0; s < KS; ++s)
+			for (int s = 0; s < KS; ++s)
 #pragma unroll
-			for (int tq = 0; tq < 4; ++tq)
+				for (int tq = 0; tq < 4; ++tq)
+					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? c0 : acc[tq][tc], 0, 0, 0);
+			return;
+		}
+		if (!PARTIAL) {
+#pragma unroll
+			for (int s = 0; s < KS; ++s)
+#pragma unroll
+				for (int tq = 0; tq < 4; ++tq)
+					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+			return;
+		}
+#pragma unroll
+		for (int tq = 0; tq < 4; ++tq) {
+			if (tq >= n_tq) {
+				acc[tq][tc] = th[tq];
+				continue;
+			}
+#pragma unroll
+			for (int s = 0; s < KS; ++s)
 				acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+		}
+	};
+	auto frag = [&](int b, int tc, int s) -> f16x8 {
+		if (PARTIAL && n_tq == 0)
+			return f16x8{};
+		return frag_at(b, tc, s);
 	};
 
 	f16x8 fb[2][KS];  // fragments of the column being multiplied / the next one
-	float bnv[4];
 #pragma unroll
 	for (int s = 0; s < KS; ++s)
-		fb[0][s] = frag_at(0, 0, s);
+		fb[0][s] = frag(0, 0, s);
 	read_bn(bnv, 0);
 	for (uint32_t t = t0; t < t1; ++t) {
 		const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;   // tile t+1
@@ -302,20 +365,20 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		// column 0 (its fragments came in during the previous step), column 1
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			fb[1][s] = (dbg & 32) ? fb[0][0] : frag_at(buf, 1, s);
+			fb[1][s] = (dbg & 32) ? fb[0][0] : frag(buf, 1, s);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_col(0, fb[0]);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			fb[0][s] = (dbg & 32) ? fb[1][0] : frag_at(buf, 2, s);
+			fb[0][s] = (dbg & 32) ? fb[1][0] : frag(buf, 2, s);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_col(1, fb[1]);
-		if (!(dbg & 4))
+		if (!SAMPLE && !(dbg & 4))
 			gmax[0] = col_max(0);
 		__builtin_amdgcn_s_setprio(0);
 		stamp(0);
 		// ---- the step's barrier: tile t+1 landed, tile t-1 released ------------------------------
-		const bool look = ++since_look == kF16FlushEvery;
+		const bool look = !SAMPLE && ++since_look == kF16FlushEvery;
 		if (look && lane == 0)
 			fills[wave] = wfill;
 		if (!(dbg & 1))
@@ -333,7 +396,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		__builtin_amdgcn_s_setprio(1);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			fb[1][s] = (dbg & 32) ? fb[0][0] : frag_at(buf, 3, s);
+			fb[1][s] = (dbg & 32) ? fb[0][0] : frag(buf, 3, s);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_col(2, fb[0]);
 		if (!(dbg & 2)) {
@@ -341,12 +404,12 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 			for (int i = 0; i < (LOADS + 1) / 2; ++i)
 				stage_piece(stb, srow0, pbuf, i);
 		}
-		if (!(dbg & 4))
+		if (!SAMPLE && !(dbg & 4))
 			gmax[1] = col_max(1);
 		// column 0 of tile t+1 and its row terms (clamped past the end: the re-staged last tile)
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
-			fb[0][s] = (dbg & 32) ? fb[1][0] : frag_at(nbuf, 0, s);
+			fb[0][s] = (dbg & 32) ? fb[1][0] : frag(nbuf, 0, s);
 		read_bn(bnn, nbuf);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_col(3, fb[1]);
@@ -355,11 +418,15 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 			for (int i = (LOADS + 1) / 2; i < LOADS; ++i)
 				stage_piece(stb, srow0, pbuf, i);
 		}
-		if (!(dbg & 4))
+		if (SAMPLE)
+			fold(0);
+		else if (!(dbg & 4))
 			gmax[2] = col_max(2);
 		__builtin_amdgcn_s_setprio(0);
 		stamp(2);
-		if (!(dbg & 4)) {
+		if (SAMPLE) {
+			fold(1);
+		} else if (!(dbg & 4)) {
 			gmax[3] = col_max(3);
 			// one wave-uniform test per step; the queue push is the rare path
 			const bool h0 = gmax[0] >= bnv[0], h1 = gmax[1] >= bnv[1], h2 = gmax[2] >= bnv[2],
@@ -374,7 +441,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 				if (k3) push_hits(acc, 3, k3, h3, bnv[3], row0);
 			}
 		}
-		if (wfill >= (uint32_t)QCAP * 3 / 4)
+		if (!SAMPLE && wfill >= (uint32_t)QCAP * 3 / 4)
 			flush_own();
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
@@ -382,11 +449,29 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		buf = nbuf;
 		stamp(3);
 	}
-	flush_own();
-	if (lane == 0) {
-		*my_log_cnt = glog_n;
-		if (glog_n > p.log_cap)  // (the log is as large as this wave's share of the candidate lists)
-			atomicAdd(p.lost, 1u);
+	};
+	if (SAMPLE || n_tq == 4)
+		run(std::false_type{});
+	else
+		run(std::true_type{});
+	if (SAMPLE) {
+#pragma unroll
+		for (int par = 0; par < 2; ++par)
+#pragma unroll
+			for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
+					if (qi < p.m)
+						p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + par * 16 + l15] = smax[par][tq][r];
+				}
+	} else {
+		flush_own();
+		if (lane == 0) {
+			*my_log_cnt = glog_n;
+			if (glog_n > p.log_cap)  // (the log is as large as this wave's share of the candidate lists)
+				atomicAdd(p.lost, 1u);
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (p.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {
