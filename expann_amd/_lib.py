@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "expann_sharded_sync", "expann_sharded_set_option", "expann_sharded_set_profiling",
     "expann_sharded_get_profile", "expann_sharded_exchange_pattern", "expann_sharded_comm_ranks",
     "expann_sharded_last_enqueue_ms", "expann_sharded_set_alltoallv_fn", "expann_sharded_search_devices",
-    "expann_sharded_slice",
+    "expann_sharded_slice", "expann_device_heap_trace",
 ]
 
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,9 +28,12 @@ struct expann_graph {
 	uint8_t* d_compressed = nullptr;
 	uint32_t* d_layer_off = nullptr;
 	uint32_t* d_neighbours = nullptr;
-	uint8_t* d_visited = nullptr;
+	uint32_t* d_adj0 = nullptr;   // [n][stride0] layer-0 lists at a fixed stride, padded with UINT32_MAX
+	uint32_t stride0 = 0;
+	uint8_t* d_visited = nullptr;  // epoch bytes [slots][n], or -- vis_words != 0 -- bitsets [slots][vis_words]
+	uint32_t vis_words = 0;
 	uint32_t* d_epochs = nullptr;
-	uint32_t* d_error = nullptr;
+	uint32_t* d_error = nullptr;   // [2]: overflow flag, query counter of the launch
 	uint32_t slots = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -51,6 +55,8 @@ struct GraphVariant {
 #define GRAPH_V(D) {D, false, graph_search_kernel<D, false>}, {D, true, graph_search_kernel<D, true>}
 const GraphVariant kGraph[] = {GRAPH_V(64), GRAPH_V(128), GRAPH_V(256), GRAPH_V(832), GRAPH_V(960)};
 #undef GRAPH_V
+// the instrumented instance (EXPANN_GRAPH_STAMPS=1, d = 128): per-phase shader clocks of a hop
+const GraphVariant kGraphDbg[] = {{128, false, graph_search_kernel<128, false, 1>}, {128, true, graph_search_kernel<128, true, 1>}};
 }  // namespace
 
 extern "C" {
@@ -132,7 +138,7 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 	if (hipMalloc(&g->d_vectors, vbytes) != hipSuccess ||
 	    hipMalloc(&g->d_layer_off, off32.size() * sizeof(uint32_t)) != hipSuccess ||
 	    hipMalloc(&g->d_neighbours, std::max<uint64_t>(n_edges, 1) * sizeof(uint32_t)) != hipSuccess ||
-	    hipMalloc(&g->d_error, sizeof(uint32_t)) != hipSuccess)
+	    hipMalloc(&g->d_error, 2 * sizeof(uint32_t)) != hipSuccess)
 		return bail("hipMalloc");
 	if (hipMemcpy(g->d_vectors, vectors, vbytes, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(g->d_layer_off, off32.data(), off32.size() * sizeof(uint32_t),
@@ -140,18 +146,35 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 	    (n_edges && hipMemcpy(g->d_neighbours, neighbours, n_edges * sizeof(uint32_t),
 	                          hipMemcpyHostToDevice) != hipSuccess))
 		return bail("hipMemcpy");
+	{
+		// layer 0 once more at a fixed stride: a hop then reads its list at cur * stride without first
+		// fetching the row's offsets (one dependent HBM round trip less per hop)
+		g->stride0 = std::max<uint32_t>(4, (g->max_degree0 + 3) / 4 * 4);
+		std::vector<uint32_t> adj((size_t)n * g->stride0, 0xFFFFFFFFu);
+		for (size_t v = 0; v < n; ++v)
+			std::copy(neighbours + off32[v], neighbours + off32[v + 1], adj.begin() + v * g->stride0);
+		if (hipMalloc(&g->d_adj0, adj.size() * sizeof(uint32_t)) != hipSuccess)
+			return bail("hipMalloc(adj0)");
+		if (hipMemcpy(g->d_adj0, adj.data(), adj.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+			return bail("hipMemcpy(adj0)");
+	}
 	// one visited array per workgroup of the (persistent) search grid; bounded to ~1/8 of a 288 GB
 	// HBM.  The walk is a chain of dependent memory round trips: what hides them is waves per CU
 	// (the kernel needs ~60 VGPRs and ~10 KB of LDS at ef = 60: 16 workgroups fit a CU).
 	const int cus = num_cus(device);
 	uint64_t slots = (uint64_t)cus * 16;
-	while (slots > 64 && slots * n > (32ull << 30))
+	// visited sets: bitsets (cleared after every query) up to 8 M vertices, epoch bytes beyond
+	g->vis_words = n <= (8u << 20) ? (uint32_t)((n + 8191) / 8192 * 256) : 0u;
+	if (std::getenv("EXPANN_GRAPH_VISITED_BYTES"))  // (A/B switch: round 2's epoch bytes at any size)
+		g->vis_words = 0;
+	const uint64_t per_slot = g->vis_words ? (uint64_t)g->vis_words * 4 : (uint64_t)n;
+	while (slots > 64 && slots * per_slot > (32ull << 30))
 		slots /= 2;
 	g->slots = (uint32_t)slots;
-	if (hipMalloc(&g->d_visited, slots * n) != hipSuccess ||
+	if (hipMalloc(&g->d_visited, slots * per_slot) != hipSuccess ||
 	    hipMalloc(&g->d_epochs, slots * sizeof(uint32_t)) != hipSuccess)
 		return bail("hipMalloc(visited)");
-	if (hipMemset(g->d_visited, 0, slots * n) != hipSuccess ||
+	if (hipMemset(g->d_visited, 0, slots * per_slot) != hipSuccess ||
 	    hipMemset(g->d_epochs, 0, slots * sizeof(uint32_t)) != hipSuccess)
 		return bail("hipMemset");
 	*out = g;
@@ -167,6 +190,7 @@ void expann_graph_destroy(expann_graph* g) {
 	if (g->d_compressed) hipFree(g->d_compressed);
 	if (g->d_layer_off) hipFree(g->d_layer_off);
 	if (g->d_neighbours) hipFree(g->d_neighbours);
+	if (g->d_adj0) hipFree(g->d_adj0);
 	if (g->d_visited) hipFree(g->d_visited);
 	if (g->d_epochs) hipFree(g->d_epochs);
 	if (g->d_error) hipFree(g->d_error);
@@ -202,6 +226,10 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 			gv = &v;
 	if (!gv)
 		return g->fail(EXPANN_ERR_UNSUPPORTED, "no graph kernel for this dim");
+	const bool stamps = std::getenv("EXPANN_GRAPH_STAMPS") != nullptr && g->dim == 128;
+	if (stamps)
+		gv = &kGraphDbg[use_compression ? 1 : 0];
+	DevBuf b_stamps;
 	if (use_compression && !g->d_compressed) {  // quantizer_simple<uint8_t>::build, :485-486
 		HIP_TRY(g, hipMalloc(&g->d_compressed, g->n * (size_t)g->dim));
 		const size_t nv = g->n * (size_t)g->dim;
@@ -221,7 +249,7 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	float* d_d = b_d.as<float>();
 	uint32_t* d_dc = b_dc.as<uint32_t>();
 	HIP_TRY(g, hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, g->stream));
-	HIP_TRY(g, hipMemsetAsync(g->d_error, 0, sizeof(uint32_t), g->stream));
+	HIP_TRY(g, hipMemsetAsync(g->d_error, 0, 2 * sizeof(uint32_t), g->stream));
 	uint32_t err_host = 0;
 	uint32_t cand_cap = 256;
 	while (cand_cap < 16 * ef_search && cand_cap < 8192)
@@ -232,6 +260,8 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 		p.compressed = g->d_compressed;
 		p.layer_off = g->d_layer_off;
 		p.neighbours = g->d_neighbours;
+		p.adj0 = g->d_adj0;
+		p.stride0 = g->stride0;
 		p.n = (uint32_t)g->n;
 		p.n_layers = g->n_layers;
 		p.starting_vertex = g->starting_vertex;
@@ -241,20 +271,36 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 		p.ef = (uint32_t)ef_search;
 		p.cand_cap = cand_cap;
 		p.max_degree = g->max_degree0;
-		p.list_cap = std::max<uint32_t>(std::max<uint32_t>(g->max_degree0, (uint32_t)ef_search), 4);
+		p.list_cap = std::max<uint32_t>(std::max<uint32_t>(g->stride0, (uint32_t)ef_search), 4);
 		p.visited = g->d_visited;
+		p.vis_bits = reinterpret_cast<uint32_t*>(g->d_visited);
+		p.vis_words = g->vis_words;
 		p.epochs = g->d_epochs;
 		p.out_ids = d_ids;
 		p.out_dists = d_d;
 		p.out_distcomps = d_dc;
 		p.error = g->d_error;
+		p.next_query = g->d_error + 1;
+		if (const char* e = std::getenv("EXPANN_GRAPH_DEBUG"))
+			p.debug = (uint32_t)std::atol(e);
+		if (stamps) {
+			if (!b_stamps.p)
+				HIP_TRY(g, b_stamps.alloc(sizeof(unsigned long long) * 8 * g->slots));
+			HIP_TRY(g, hipMemsetAsync(b_stamps.p, 0, sizeof(unsigned long long) * 8 * g->slots, g->stream));
+			p.stamps = b_stamps.as<unsigned long long>();
+		}
 		const size_t lds = sizeof(md_pair) * (p.ef + 1 + p.cand_cap + 1) +
-		                   (sizeof(uint32_t) + sizeof(float)) * p.list_cap + 8 * sizeof(uint32_t);
+		                   (sizeof(uint32_t) + sizeof(float)) * p.list_cap;
 		if (lds > 160 * 1024)
 			return g->fail(EXPANN_ERR_UNSUPPORTED, "graph search working set exceeds LDS");
 		HIP_TRY(g, hipFuncSetAttribute((const void*)gv->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
 		                               (int)lds));
-		const uint32_t grid = (uint32_t)std::min<size_t>(m, g->slots);
+		// as many workgroups as are resident at once (registers and LDS of this instance), each with a
+		// visited array of its own; they pull queries from a counter
+		int per_cu = 0;
+		HIP_TRY(g, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gv->fn, 64, lds));
+		const uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)num_cus(g->device);
+		const uint32_t grid = (uint32_t)std::min<size_t>(m, std::min<uint32_t>(g->slots, resident));
 		HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 		hipLaunchKernelGGL(gv->fn, dim3(grid), dim3(64), lds, g->stream, p);
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
@@ -265,12 +311,30 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 		float ms = 0;
 		HIP_TRY(g, hipEventElapsedTime(&ms, g->ev0, g->ev1));
 		g->last_ms = ms;
+		if (stamps) {  // mean over the workgroups of the grid, per hop
+			std::vector<unsigned long long> st(8 * (size_t)grid);
+			HIP_TRY(g, hipMemcpy(st.data(), b_stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+			double tot[8] = {0};
+			for (uint32_t b = 0; b < grid; ++b)
+				for (int i = 0; i < 8; ++i)
+					tot[i] += (double)st[8 * (size_t)b + i];
+			const double hops = tot[6] > 0 ? tot[6] : 1, all = tot[0] + tot[1] + tot[2] + tot[3] + tot[4] + tot[5];
+			std::fprintf(stderr,
+			             "graph_search<%d,%s> ef %zu: %.3f ms, %u workgroups, %.1f hops / query, %.1f queue insertions / hop; "
+			             "shader clocks per hop: pop + broadcast %.0f, adjacency + visited %.0f, gathers + scoring %.0f, "
+			             "serial queue update %.0f; per query: setup + descent %.0f, output %.0f; shares %.1f / %.1f / %.1f / "
+			             "%.1f / %.1f / %.1f %%\n",
+			             g->dim, use_compression ? "u8" : "f32", ef_search, ms, grid, tot[6] / (double)m, tot[7] / hops,
+			             tot[1] / hops, tot[2] / hops, tot[3] / hops, tot[4] / hops, tot[0] / (double)m, tot[5] / (double)m,
+			             100 * tot[1] / all, 100 * tot[2] / all, 100 * tot[3] / all, 100 * tot[4] / all, 100 * tot[0] / all,
+			             100 * tot[5] / all);
+		}
 		if (!err_host || cand_cap >= 8192)
 			break;
 		cand_cap *= 4;  // a candidates heap overflowed: retry with a larger one
 		if (cand_cap > 8192)
 			cand_cap = 8192;
-		HIP_TRY(g, hipMemsetAsync(g->d_error, 0, sizeof(uint32_t), g->stream));
+		HIP_TRY(g, hipMemsetAsync(g->d_error, 0, 2 * sizeof(uint32_t), g->stream));
 	}
 	HIP_TRY(g, hipMemcpy(ids, d_ids, sizeof(uint64_t) * m * k, hipMemcpyDeviceToHost));
 	HIP_TRY(g, hipMemcpy(dists, d_d, sizeof(float) * m * k, hipMemcpyDeviceToHost));
@@ -279,6 +343,55 @@ int expann_graph_search(expann_graph* g, const float* queries, size_t m, size_t 
 	if (err_host)
 		return g->fail(EXPANN_ERR_OVERFLOW, "graph search: candidates queue overflowed its LDS capacity");
 	return EXPANN_OK;
+}
+
+// test hook: a queue trace through the device's wave-cooperative heap code (tests/test_heap_pin.py);
+// the signature of oracle_heap_trace / std_heap_trace, ids must fit 32 bits
+size_t expann_device_heap_trace(int max_heap, size_t n_init, const float* init_d, const uint64_t* init_id, size_t n_ops,
+                                const int* ops, const float* op_d, const uint64_t* op_id, uint64_t* out_size,
+                                float* out_top_d, uint64_t* out_top_id, float* drain_d, uint64_t* drain_id) {
+	const size_t cap = n_init + n_ops + 1;
+	if (cap * sizeof(md_pair) > (60u << 10) || hipSetDevice(0) != hipSuccess)
+		return (size_t)-1;
+	std::vector<uint32_t> id32(n_init), opid32(n_ops);
+	for (size_t i = 0; i < n_init; ++i)
+		id32[i] = (uint32_t)init_id[i];
+	for (size_t i = 0; i < n_ops; ++i)
+		opid32[i] = (uint32_t)op_id[i];
+	DevBuf b_id, b_ii, b_ops, b_od, b_oi, b_sz, b_td, b_ti, b_dd, b_di, b_n;
+	if (b_id.alloc(4 * n_init) != hipSuccess || b_ii.alloc(4 * n_init) != hipSuccess || b_ops.alloc(4 * n_ops) != hipSuccess ||
+	    b_od.alloc(4 * n_ops) != hipSuccess || b_oi.alloc(4 * n_ops) != hipSuccess || b_sz.alloc(4 * (n_ops + 1)) != hipSuccess ||
+	    b_td.alloc(4 * (n_ops + 1)) != hipSuccess || b_ti.alloc(4 * (n_ops + 1)) != hipSuccess ||
+	    b_dd.alloc(4 * cap) != hipSuccess || b_di.alloc(4 * cap) != hipSuccess || b_n.alloc(4) != hipSuccess)
+		return (size_t)-1;
+	hipMemcpy(b_id.p, init_d, 4 * n_init, hipMemcpyHostToDevice);
+	hipMemcpy(b_ii.p, id32.data(), 4 * n_init, hipMemcpyHostToDevice);
+	hipMemcpy(b_ops.p, ops, 4 * n_ops, hipMemcpyHostToDevice);
+	hipMemcpy(b_od.p, op_d, 4 * n_ops, hipMemcpyHostToDevice);
+	hipMemcpy(b_oi.p, opid32.data(), 4 * n_ops, hipMemcpyHostToDevice);
+	HeapTraceParams p{max_heap, (uint32_t)n_init, (uint32_t)n_ops, b_id.as<float>(), b_ii.as<uint32_t>(), b_ops.as<int>(),
+	                  b_od.as<float>(), b_oi.as<uint32_t>(), b_sz.as<uint32_t>(), b_td.as<float>(), b_ti.as<uint32_t>(),
+	                  b_dd.as<float>(), b_di.as<uint32_t>(), b_n.as<uint32_t>(), 0u};
+	if (const char* e = std::getenv("EXPANN_GRAPH_DEBUG"))
+		p.serial = (uint32_t)std::atol(e) & 1u;
+	hipLaunchKernelGGL(heap_trace_kernel, dim3(1), dim3(64), cap * sizeof(md_pair), nullptr, p);
+	if (hipDeviceSynchronize() != hipSuccess)
+		return (size_t)-1;
+	std::vector<uint32_t> sz(n_ops + 1), ti(n_ops + 1), di(cap);
+	uint32_t nd = 0;
+	hipMemcpy(sz.data(), b_sz.p, 4 * (n_ops + 1), hipMemcpyDeviceToHost);
+	hipMemcpy(out_top_d, b_td.p, 4 * (n_ops + 1), hipMemcpyDeviceToHost);
+	hipMemcpy(ti.data(), b_ti.p, 4 * (n_ops + 1), hipMemcpyDeviceToHost);
+	hipMemcpy(&nd, b_n.p, 4, hipMemcpyDeviceToHost);
+	hipMemcpy(drain_d, b_dd.p, 4 * (size_t)nd, hipMemcpyDeviceToHost);
+	hipMemcpy(di.data(), b_di.p, 4 * (size_t)nd, hipMemcpyDeviceToHost);
+	for (size_t i = 0; i <= n_ops; ++i) {
+		out_size[i] = sz[i];
+		out_top_id[i] = ti[i];
+	}
+	for (uint32_t i = 0; i < nd; ++i)
+		drain_id[i] = di[i];
+	return nd;
 }
 
 // ---- GPU-assisted batched construction (graph_build.hpp) -------------------------------------

@@ -291,6 +291,17 @@ int expann_antitopo_load(expann_antitopo* e, const char* index_path);  /* deseri
 size_t expann_antitopo_size(const expann_antitopo* e);
 uint64_t expann_antitopo_num_distcomps(const expann_antitopo* e);
 
+/* test hook: replays a trace of priority-queue operations through the device's wave-cooperative heap code
+ * (csrc/graph_search.hpp coop_push / coop_pop, the walk's queues) on device 0.  Same signature and output
+ * format as the oracle's oracle_heap_trace: ops[i] 1 = push (op_d[i], op_id[i]), 0 = pop; entry 0 of the
+ * out_* arrays is the state after the range constructor, entry i + 1 the state after op i; returns the
+ * drain length, (size_t)-1 on failure.  tests/test_heap_pin.py checks it against the traces the image's
+ * real std::priority_queue answered (tests/golden/heap_ref.json). */
+size_t expann_device_heap_trace(int max_heap, size_t n_init, const float* init_d, const uint64_t* init_id,
+                                size_t n_ops, const int* ops, const float* op_d, const uint64_t* op_id,
+                                uint64_t* out_size, float* out_top_d, uint64_t* out_top_id, float* drain_d,
+                                uint64_t* drain_id);
+
 /* quantiser builds on device buffers (src/quantizer.h) -------------------------------- */
 /* quantizer_simple<uint8_t>::build (src/quantizer.h:132-141): out[i] = uint8_t(in[i]), no
  * scaling; defined for 0 <= in[i] < 256.  Asynchronous on `stream`. */

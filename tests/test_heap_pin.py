@@ -64,6 +64,18 @@ def test_golden_is_what_this_box_libstdcxx_does(cases, tmp_path):
 
 
 @pytest.mark.gpu
+def test_device_coop_heap_equals_libstdcxx(cases, oracle):
+    """The walk's queues themselves: every golden trace replayed through the device's wave-cooperative
+    push / pop (csrc/graph_search.hpp coop_push, coop_pop; expann_device_heap_trace) must leave the states
+    and the drain order the image's std::priority_queue left -- ties, range construction, long queues."""
+    from expann_amd import _lib
+    lib = _lib.load()
+    lib.expann_device_heap_trace.restype = C.c_size_t
+    lib.expann_device_heap_trace.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+    _check(cases, lib.expann_device_heap_trace, oracle)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("levels,M", [(2, 16), (4, 40)])
 def test_device_heap_on_massive_ties(tmp_path, oracle, levels, M):
     """uint8 rows with `levels` distinct values per component: every distance is a small integer
