@@ -53,7 +53,8 @@ struct GraphVariant {
 	GraphFn fn;
 };
 #define GRAPH_V(D) {D, false, graph_search_kernel<D, false>}, {D, true, graph_search_kernel<D, true>}
-const GraphVariant kGraph[] = {GRAPH_V(64), GRAPH_V(128), GRAPH_V(256), GRAPH_V(832), GRAPH_V(960)};
+const GraphVariant kGraph[] = {GRAPH_V(64),  GRAPH_V(128), GRAPH_V(256), GRAPH_V(512),
+                               GRAPH_V(768), GRAPH_V(832), GRAPH_V(960)};
 #undef GRAPH_V
 // the instrumented instance (EXPANN_GRAPH_STAMPS=1, d = 128): per-phase shader clocks of a hop
 const GraphVariant kGraphDbg[] = {{128, false, graph_search_kernel<128, false, 1>}, {128, true, graph_search_kernel<128, true, 1>}};
@@ -89,7 +90,7 @@ int expann_graph_create(int dim, int device, const float* vectors, size_t n, uin
 	for (const auto& v : kGraph)
 		dim_ok |= v.d == dim;
 	if (!dim_ok) {
-		g_create_error = "graph search is built for dim 64, 128, 256, 832, 960";
+		g_create_error = "graph search is built for dim 64, 128, 256, 512, 768, 832, 960";
 		return EXPANN_ERR_UNSUPPORTED;
 	}
 	const uint64_t n_edges = layer_offsets[(size_t)n_layers * (n + 1) - 1];
@@ -404,7 +405,8 @@ struct BuildVariant {
 	BuildPruneFn prune;
 };
 #define BUILD_V(D) {D, build_search_kernel<D>, build_prune_kernel<D>}
-const BuildVariant kBuild[] = {BUILD_V(64), BUILD_V(128), BUILD_V(256), BUILD_V(832), BUILD_V(960)};
+const BuildVariant kBuild[] = {BUILD_V(64),  BUILD_V(128), BUILD_V(256), BUILD_V(512),
+                               BUILD_V(768), BUILD_V(832), BUILD_V(960)};
 #undef BUILD_V
 struct BuildFail {
 	std::string msg;
@@ -422,7 +424,7 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 		if (v.d == dim)
 			bv = &v;
 	if (!bv) {
-		g_create_error = "graph build is compiled for dim 64, 128, 256, 832, 960";
+		g_create_error = "graph build is compiled for dim 64, 128, 256, 512, 768, 832, 960";
 		return EXPANN_ERR_UNSUPPORTED;
 	}
 	if (!vectors || !levels || !max_layer_io || !starting_vertex_io || !ids0 || !d0 || !deg0 || !upper_idx ||
@@ -455,7 +457,7 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 	} sg;
 	HIP_TRY(fh, hipStreamCreate(&sg.s));
 	hipStream_t st = sg.s;
-	DevBuf b_vec, b_lvl, b_up, b_id0, b_d0, b_deg0, b_idu, b_du, b_degu, b_vis, b_ep, b_out, b_outc, b_tasks, b_upslot,
+	DevBuf b_vec, b_lvl, b_up, b_id0, b_d0, b_deg0, b_idu, b_du, b_degu, b_vis, b_out, b_outc, b_tasks, b_upslot,
 	    b_dirty, b_ctr;
 	const size_t n_up_rows = U * n_upper_layers;
 	HIP_TRY(fh, b_vec.alloc(n * (size_t)dim * 4));
@@ -505,12 +507,10 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 	                          (sizeof(uint32_t) + sizeof(float)) * list_cap + 8 * sizeof(uint32_t);
 	HIP_TRY(fh, hipFuncSetAttribute((const void*)bv->search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)search_lds));
 	uint64_t slots = (uint64_t)cus * 2;  // resident search workgroups (two 72 KB workgroups per CU)
-	while (slots > 64 && slots * n > (32ull << 30))
-		slots /= 2;
-	HIP_TRY(fh, b_vis.alloc(slots * n));
-	HIP_TRY(fh, b_ep.alloc(slots * 4));
-	HIP_TRY(fh, hipMemset(b_vis.p, 0, slots * n));
-	HIP_TRY(fh, hipMemset(b_ep.p, 0, slots * 4));
+	// one visited bitset per resident workgroup, all zero between searches (graph_search.hpp)
+	const uint32_t vis_words = (uint32_t)((n + 8191) / 8192 * 256);
+	HIP_TRY(fh, b_vis.alloc(slots * vis_words * 4));
+	HIP_TRY(fh, hipMemset(b_vis.p, 0, slots * vis_words * 4));
 	const size_t max_up_in_batch = max_batch * (n_upper_layers ? 1 : 0) + 64;  // (bounded below per batch)
 	HIP_TRY(fh, b_out.alloc((max_batch + max_up_in_batch) * ef_construction * sizeof(md_pair)));
 	HIP_TRY(fh, b_outc.alloc((max_batch + max_up_in_batch) * 4));
@@ -568,8 +568,8 @@ int expann_graph_build_batched(int dim, int device, const float* vectors, size_t
 		sp.ef = (uint32_t)ef_construction;
 		sp.cand_cap = cand_cap;
 		sp.list_cap = list_cap;
-		sp.visited = b_vis.as<uint8_t>();
-		sp.epochs = b_ep.as<uint32_t>();
+		sp.vis_bits = b_vis.as<uint32_t>();
+		sp.vis_words = vis_words;
 		sp.up_slot = b_upslot.as<int32_t>();
 		sp.out = b_out.as<md_pair>();
 		sp.out_cnt = b_outc.as<uint32_t>();

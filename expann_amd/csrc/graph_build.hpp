@@ -63,8 +63,8 @@ struct BuildSearchParams {
 	uint32_t max_layer, starting_vertex;
 	uint32_t ef;                  // ef_construction
 	uint32_t cand_cap, list_cap;  // LDS capacities: candidates heap, neighbour list of a hop
-	uint8_t* visited;             // [gridDim.x][n] epoch bytes
-	uint32_t* epochs;             // [gridDim.x]
+	uint32_t* vis_bits;           // [gridDim.x][vis_words] visited bitsets, all zero between searches
+	uint32_t vis_words;           // a multiple of 256
 	// results: list of (v, layer) = out + slot * ef entries, slot = v - b0 for layer 0, else
 	// up_slot[v - b0] + layer - 1 behind the (b1 - b0) layer-0 slots
 	const int32_t* up_slot;       // [b1 - b0] or -1
@@ -76,31 +76,50 @@ struct BuildSearchParams {
 template <int D>
 __global__ __launch_bounds__(64) void build_search_kernel(BuildSearchParams p) {
 	constexpr int DPL = D / 16;
+	constexpr int U = graph_rows_f32<D>();  // rows in flight per 16-lane group
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	md_pair* nearest = reinterpret_cast<md_pair*>(smem_raw);             // [ef + 1]
 	md_pair* candidates = nearest + (p.ef + 1);                          // [cand_cap + 1]
 	uint32_t* nlist = reinterpret_cast<uint32_t*>(candidates + (p.cand_cap + 1));  // [list_cap]
 	float* ndist = reinterpret_cast<float*>(nlist + p.list_cap);
-	uint32_t* ctl = reinterpret_cast<uint32_t*>(ndist + p.list_cap);
 	const int lane = threadIdx.x;
 	const int l = lane & 15, rg = lane >> 4;
-	uint8_t* visited = p.visited + (size_t)blockIdx.x * p.g.n;
-	uint32_t epoch = p.epochs[blockIdx.x];
+	// visited set of this workgroup: a bitset, all zero between searches (graph_search.hpp)
+	uint32_t* vbits = p.vis_bits + (size_t)blockIdx.x * p.vis_words;
+	uint32_t overflowed = 0;
 
 	for (uint32_t v = p.b0 + blockIdx.x; v < p.b1; v += gridDim.x) {
 		float q[DPL];
 #pragma unroll
 		for (int t = 0; t < DPL; ++t)
 			q[t] = p.g.vec[(size_t)v * D + l + 16 * t];
-		auto dist_f32 = [&](uint32_t row) -> float {
-			const float* r = p.g.vec + (size_t)row * D + l;
-			float acc = 0.0f;
+		// exact fp32 squared L2 of the new vertex against UU rows per 16-lane group (reference order), all
+		// rows requested before the first is consumed
+		auto dist_rows = [&](auto u_tag, const uint32_t* rows, float* d) {
+			constexpr int UU = decltype(u_tag)::value;
+			float r[UU][DPL];
 #pragma unroll
-			for (int t = 0; t < DPL; ++t) {
-				const float diff = q[t] - r[16 * t];
-				acc = __builtin_fmaf(diff, diff, acc);
+			for (int u = 0; u < UU; ++u) {
+				const float* src = p.g.vec + (size_t)rows[u] * D + l;
+#pragma unroll
+				for (int t = 0; t < DPL; ++t)
+					r[u][t] = src[16 * t];
 			}
-			return reduce16_ref_order(acc);
+#pragma unroll
+			for (int u = 0; u < UU; ++u) {
+				float acc = 0.0f;
+#pragma unroll
+				for (int t = 0; t < DPL; ++t) {
+					const float diff = q[t] - r[u][t];
+					acc = __builtin_fmaf(diff, diff, acc);
+				}
+				d[u] = reduce16_ref_order(acc);
+			}
+		};
+		auto dist_f32 = [&](uint32_t row) -> float {
+			float d1[1];
+			dist_rows(std::integral_constant<int, 1>{}, &row, d1);
+			return d1[0];
 		};
 		const uint32_t lv = p.g.level[v];
 		// greedy descent through the layers above the new vertex's level (:343-357, one entry point)
@@ -112,156 +131,160 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildSearchParams p) {
 				changed = false;
 				const uint32_t* nb_ids = p.g.ids(layer, entry);
 				const uint32_t deg = min(*p.g.deg(layer, entry), p.g.stride(layer));
-				float best = ep_dist;
-				uint32_t best_id = entry;
-				for (uint32_t i0 = 0; i0 < deg; i0 += 4) {
-					const uint32_t i = i0 + rg;
-					const uint32_t nb = nb_ids[i < deg ? i : deg - 1];
-					const float d = dist_f32(nb);
+				// first-improvement chain == first occurrence of the minimum, if it improves
+				uint64_t best_key = ~0ull;
+				uint32_t best_nb = 0;
+				for (uint32_t i0 = 0; i0 < deg; i0 += 4 * U) {
+					uint32_t nb[U];
+					float d[U];
 #pragma unroll
-					for (int g = 0; g < 4; ++g) {
-						const float dg = __shfl(d, g * 16);
-						const uint32_t ng = __shfl(nb, g * 16);
-						if (i0 + g < deg && dg < best) {
-							best = dg;
-							best_id = ng;
-							changed = true;
+					for (int u = 0; u < U; ++u) {
+						const uint32_t i = i0 + 4 * u + rg;
+						nb[u] = nb_ids[i < deg ? i : deg - 1];
+					}
+					dist_rows(std::integral_constant<int, U>{}, nb, d);
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const uint32_t i = i0 + 4 * u + rg;
+						const uint64_t key = ((uint64_t)__builtin_bit_cast(uint32_t, d[u]) << 32) | i;
+						if (i < deg && key < best_key) {
+							best_key = key;
+							best_nb = nb[u];
 						}
 					}
 				}
-				entry = best_id;
-				ep_dist = best;
+				const uint64_t wmin = wave_min_key64(best_key);
+				const float dmin = __builtin_bit_cast(float, (uint32_t)(wmin >> 32));
+				if (wmin != ~0ull && dmin < ep_dist) {
+					const unsigned long long who = __builtin_amdgcn_ballot_w64(best_key == wmin);
+					entry = (uint32_t)__builtin_amdgcn_readlane((int)best_nb, __builtin_ctzll(who));
+					ep_dist = dmin;
+					changed = true;
+				}
 			}
 		}
 		// ef_construction search of every layer the vertex joins, top down (:364-387, ortho_count 1:
-		// one seed, plain distances; the next layer starts at this layer's nearest)
+		// one seed, plain distances; the next layer starts at this layer's nearest).  The queues are
+		// updated by the whole wave (graph_search.hpp: coop_push / coop_pop, libstdc++'s movement).
 		const uint32_t top = lv < p.max_layer - 1 ? lv : p.max_layer - 1;
 		for (uint32_t layer = top; layer <= top; --layer) {
-			if (++epoch > 255) {
-				for (uint32_t i = lane; i < p.g.n; i += 64)
-					visited[i] = 0;
-				epoch = 1;
-			}
-			const uint8_t ep8 = (uint8_t)epoch;
-			uint32_t n_near = 0, n_cand = 0;
+			uint32_t n_near = 0, n_cand = 0;  // wave-uniform
 			const float d_entry = dist_f32(entry);
-			if (lane == 0) {
+			{
 				const md_pair e{d_entry, entry};
-				heap_push<false>(candidates, n_cand, e);
-				heap_push<true>(nearest, n_near, e);
-				visited[entry] = ep8;
+				coop_push<false>(candidates, n_cand, e, lane);
+				coop_push<true>(nearest, n_near, e, lane);
+				if (lane == 0)
+					atomicOr(&vbits[entry >> 5], 1u << (entry & 31));
 			}
-			__syncthreads();
+			wave_lds_sync();
 			for (;;) {
-				if (lane == 0) {
-					uint32_t go = 0, cur_id = 0;
-					if (n_cand > 0) {
-						const md_pair cur = candidates[0];
-						heap_pop<false>(candidates, n_cand);
-						if (!(cur.d > nearest[0].d && n_near == p.ef)) {
-							go = 1;
-							cur_id = cur.id;
-						}
-					}
-					ctl[1] = go;
-					ctl[2] = cur_id;
-					ctl[3] = __builtin_bit_cast(uint32_t, nearest[0].d);
-					ctl[4] = n_near;
-				}
-				__syncthreads();
-				if (!ctl[1])
+				if (n_cand == 0)
 					break;
-				const uint32_t cur_id = ctl[2];
-				const float worst0 = __builtin_bit_cast(float, ctl[3]);
-				const bool full0 = ctl[4] == p.ef;
-				const uint32_t* nb_ids = p.g.ids(layer, cur_id);
-				const uint32_t deg = min(*p.g.deg(layer, cur_id), p.g.stride(layer));
+				const md_pair cur = candidates[0];
+				coop_pop<false>(candidates, n_cand, lane);
+				const float worst0 = nearest[0].d;
+				const bool full0 = n_near == p.ef;
+				if (cur.d > worst0 && full0)
+					break;
+				const uint32_t* nb_ids = p.g.ids(layer, cur.id);
+				const uint32_t deg = min(*p.g.deg(layer, cur.id), p.g.stride(layer));
 				uint32_t n_list = 0;
-				for (uint32_t i0 = 0; i0 < deg; i0 += 64) {
-					const uint32_t i = i0 + lane;
-					uint32_t nb = 0;
-					bool fresh = false;
-					if (i < deg) {
-						nb = nb_ids[i];
-						fresh = visited[nb] != ep8;
-						if (fresh)
-							visited[nb] = ep8;
+				for (uint32_t i0 = 0; i0 < deg; i0 += 128) {  // two halves requested before either is consumed
+					uint32_t nbv[2];
+					bool fresh[2];
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const uint32_t i = i0 + 64u * h + lane;
+						nbv[h] = i < deg ? nb_ids[i] : 0xFFFFFFFFu;
 					}
-					const unsigned long long mask = __builtin_amdgcn_ballot_w64(fresh);
-					if (fresh)
-						nlist[n_list + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = nb;
-					n_list += (uint32_t)__builtin_popcountll(mask);
+#pragma unroll
+					for (int h = 0; h < 2; ++h)
+						fresh[h] = nbv[h] != 0xFFFFFFFFu &&
+						           (atomicOr(&vbits[nbv[h] >> 5], 1u << (nbv[h] & 31)) & (1u << (nbv[h] & 31))) == 0;
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const unsigned long long mask = __builtin_amdgcn_ballot_w64(fresh[h]);
+						if (fresh[h])
+							nlist[n_list + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = nbv[h];
+						n_list += (uint32_t)__builtin_popcountll(mask);
+					}
 				}
-				__syncthreads();
-				for (uint32_t i0 = 0; i0 < n_list; i0 += 16) {  // 4 steps' rows in flight (graph_search.hpp)
-					constexpr int U = 4;
+				wave_lds_sync();
+				for (uint32_t i0 = 0; i0 < n_list; i0 += 4 * U) {
 					uint32_t nbu[U];
-					float r[U][DPL];
+					float d[U];
 #pragma unroll
 					for (int u = 0; u < U; ++u) {
 						const uint32_t i = i0 + 4 * u + rg;
 						nbu[u] = nlist[i < n_list ? i : n_list - 1];
 					}
+					dist_rows(std::integral_constant<int, U>{}, nbu, d);
 #pragma unroll
 					for (int u = 0; u < U; ++u) {
-						const float* src = p.g.vec + (size_t)nbu[u] * D + l;
-#pragma unroll
-						for (int t = 0; t < DPL; ++t)
-							r[u][t] = src[16 * t];
-					}
-#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						float acc = 0.0f;
-#pragma unroll
-						for (int t = 0; t < DPL; ++t) {
-							const float diff = q[t] - r[u][t];
-							acc = __builtin_fmaf(diff, diff, acc);
-						}
-						const float d = reduce16_ref_order(acc);
 						const uint32_t i = i0 + 4 * u + rg;
 						if (l == 0 && i < n_list)
-							ndist[i] = d;
+							ndist[i] = d[u];
 					}
 				}
-				__syncthreads();
-				if (lane == 0) {
-					for (uint32_t i = 0; i < n_list; ++i) {
-						const float dn = ndist[i];
-						if (full0 && !(dn < worst0))
-							continue;
-						if (n_near < p.ef || dn < nearest[0].d) {
-							const md_pair e{dn, nlist[i]};
-							if (n_cand >= p.cand_cap)
-								atomicAdd(p.error, 1u);
-							else
-								heap_push<false>(candidates, n_cand, e);
-							heap_push<true>(nearest, n_near, e);
-							if (n_near > p.ef)
-								heap_pop<true>(nearest, n_near);
-						}
+				wave_lds_sync();
+				// pre-filter (all lanes), compacted in list order; then one wave-wide queue operation each
+				uint32_t n_s = 0;
+				for (uint32_t i0 = 0; i0 < n_list; i0 += 64) {
+					const uint32_t i = i0 + lane;
+					const uint32_t id = i < n_list ? nlist[i] : 0u;
+					const float dn = i < n_list ? ndist[i] : 0.0f;
+					const bool keep = i < n_list && !(full0 && !(dn < worst0));
+					wave_lds_sync();
+					const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+					const uint32_t pos = n_s + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+					if (keep) {
+						nlist[pos] = id;
+						ndist[pos] = dn;
+					}
+					n_s += (uint32_t)__builtin_popcountll(mask);
+				}
+				wave_lds_sync();
+				for (uint32_t j = 0; j < n_s; ++j) {
+					const float dn = ndist[j];
+					if (n_near < p.ef || dn < nearest[0].d) {
+						const md_pair e{dn, nlist[j]};
+						if (n_cand >= p.cand_cap)
+							overflowed = 1;
+						else
+							coop_push<false>(candidates, n_cand, e, lane);
+						coop_push<true>(nearest, n_near, e, lane);
+						wave_lds_sync();
+						if (n_near > p.ef)
+							coop_pop<true>(nearest, n_near, lane);
 					}
 				}
-				__syncthreads();
+				wave_lds_sync();
 			}
 			// drain (worst first), write ascending
 			const uint32_t slot = layer == 0 ? v - p.b0 : (p.b1 - p.b0) + (uint32_t)p.up_slot[v - p.b0] + layer - 1;
 			md_pair* out = p.out + (size_t)slot * p.ef;
-			if (lane == 0) {
-				const uint32_t cnt = n_near;
-				for (uint32_t i = cnt; i-- > 0;) {
-					out[i] = nearest[0];
-					heap_pop<true>(nearest, n_near);
-				}
-				p.out_cnt[slot] = cnt;
-				ctl[2] = out[0].id;
+			const uint32_t cnt = n_near;
+			for (uint32_t i = cnt; i-- > 0;) {
+				const md_pair t = nearest[0];
+				coop_pop<true>(nearest, n_near, lane);
+				if (lane == 0)
+					out[i] = t;
+				if (i == 0)
+					entry = t.id;
 			}
-			__syncthreads();
-			entry = ctl[2];
-			__syncthreads();
+			if (lane == 0)
+				p.out_cnt[slot] = cnt;
+			// the visited set goes back to all-zero for the next search
+			uint4* w = reinterpret_cast<uint4*>(vbits);
+			for (uint32_t i = lane; i < p.vis_words / 4; i += 64)
+				w[i] = make_uint4(0u, 0u, 0u, 0u);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clear lands before the next search's test-and-sets)
+			wave_lds_sync();
 		}
 	}
-	if (lane == 0)
-		p.epochs[blockIdx.x] = epoch;
+	if (lane == 0 && overflowed)
+		atomicAdd(p.error, 1u);
 }
 
 // ---- prune ---------------------------------------------------------------------------------------

@@ -219,6 +219,37 @@ __device__ inline void coop_adjust(md_pair* v, uint32_t len, md_pair value, int 
 	else if ((uint32_t)lane == settle)
 		v[my_c] = value;
 }
+// the same for any length: the chain of larger children is walked one level at a time (every lane reads
+// the same two children: LDS broadcasts), the tail is coop_adjust's
+template <bool MAXH> __device__ inline void coop_adjust_deep(md_pair* v, uint32_t len, md_pair value, int lane) {
+	const uint32_t half = (len - 1) / 2;
+	uint32_t cur = 0, depth = 0, my_c = 0, my_cn = 0;
+	auto step_to = [&](uint32_t nxt) {
+		++depth;
+		if ((uint32_t)lane == depth)
+			my_c = nxt;
+		if ((uint32_t)lane + 1 == depth)
+			my_cn = nxt;
+		cur = nxt;
+	};
+	while (cur < half) {
+		const uint32_t c2 = 2 * cur + 2;
+		const float a = v[c2 - 1].d, b = v[c2].d;
+		step_to((MAXH ? (b < a) : (b > a)) ? c2 - 1 : c2);
+	}
+	if ((len & 1) == 0 && cur == (len - 2) / 2)
+		step_to(2 * cur + 1);
+	const bool on_chain = (uint32_t)lane < depth;
+	const md_pair z = v[on_chain ? my_cn : 0];
+	wave_lds_sync();
+	const unsigned long long rises = __builtin_amdgcn_ballot_w64(on_chain && md_less<MAXH>(z, value));
+	const unsigned long long stay = ~rises & ((depth >= 64 ? 0ull : (1ull << depth)) - 1ull);
+	const uint32_t settle = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;
+	if ((uint32_t)lane < settle)
+		v[my_c] = z;
+	else if ((uint32_t)lane == settle)
+		v[my_c] = value;
+}
 // std::pop_heap + pop_back
 template <bool MAXH> __device__ inline void coop_pop(md_pair* v, uint32_t& n, int lane, uint32_t serial = 0) {
 	if (n > 1) {
@@ -234,10 +265,8 @@ template <bool MAXH> __device__ inline void coop_pop(md_pair* v, uint32_t& n, in
 			coop_adjust<MAXH, 1>(v, len, value, lane);
 		} else if (len <= 513) {
 			coop_adjust<MAXH, 4>(v, len, value, lane);
-		} else {  // very long queues: the serial code (same movement)
-			wave_lds_sync();
-			if (lane == 0)
-				heap_adjust<MAXH>(v, 0, len, value);
+		} else {  // long queues (the builder's candidates at ef_construction = 480): walk the chain level by level
+			coop_adjust_deep<MAXH>(v, len, value, lane);
 		}
 		wave_lds_sync();
 	}

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 
-_SUPPORTED_DIMS = (64, 128, 256)
+_SUPPORTED_DIMS = (64, 128, 256, 512, 768, 832, 960)
 
 
 class AntitopoEngine:

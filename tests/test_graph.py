@@ -57,7 +57,8 @@ def test_strided_view_of_the_graph_is_lossless(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("data,d", [("sift", 128), ("gauss", 64), ("sift", 960), ("sift", 832)])
+@pytest.mark.parametrize("data,d", [("sift", 128), ("gauss", 64), ("sift", 960), ("sift", 832), ("sift", 512), ("sift", 768),
+                                    ("sift", 256)])
 def test_gpu_traversal_matches_oracle(tmp_path, oracle, data, d):
     idx, qf, rf = tmp_path / "g.index", tmp_path / "g.queries", tmp_path / "g.results"
     n, m, k = 1500, 64, 10
@@ -238,3 +239,33 @@ def test_c4_scale_properties(tmp_path):
         assert (np.diff(dd, axis=1) >= 0).all() or c == 1   # (uint8 walk: order of the uint8 distances, fp32 re-score)
         srt = np.sort(ids, axis=1)
         assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate ids (basic_bench.h:98-104)"
+
+
+@pytest.mark.gpu
+def test_ortho_count_above_one_takes_the_serial_builder(tmp_path, oracle):
+    """ortho_count > 1 (several "ortho" entry points per layer, src/antitopo_engine.h:336-379,396-413): the
+    batched GPU builder implements the reference sweep's ortho_count = 1 only, so store_many_vectors_batched
+    hands such an engine to the serial restatement -- the index file is byte-identical to the serial
+    engine's, and the GPU walk of it equals the oracle's."""
+    from expann_amd import AntitopoEngine
+    from graph_helpers import check_against_oracle
+    rng = np.random.RandomState(5)
+    base = _sift_like(rng, 1200, 128)
+    q = _sift_like(rng, 48, 128)
+    files = []
+    engs = {}
+    for batched in (False, True):
+        eng = AntitopoEngine(16, 80, 3, 0, False, dim=128)
+        if batched:
+            eng.store_many_vectors_batched(base, False, 256)
+        else:
+            eng.store_many_vectors(base, False)
+        eng.build()
+        path = str(tmp_path / f"ortho3_{int(batched)}.index")
+        eng.save_index(path)
+        files.append(open(path, "rb").read())
+        engs[batched] = eng
+    assert files[0] == files[1]
+    engc = AntitopoEngine(16, 80, 3, 0, True, dim=128)
+    engc.load_index(str(tmp_path / "ortho3_1.index"))
+    check_against_oracle(oracle, {False: engs[True], True: engc}, str(tmp_path / "ortho3_1.index"), q, 10, efs=(10, 40))
