@@ -26,7 +26,6 @@
 #include "scan_gemm_f16y.hpp"
 #include "scan_gemm_f16kx.hpp"
 #include "scan_direct_f16.hpp"
-#include "scan_gemm_f32.hpp"
 #include "scan_gemm_i8.hpp"
 #include "scan_gemm_i8q.hpp"
 #include "scan_gemm_i8x.hpp"
@@ -382,9 +381,10 @@ struct GemmVariant {
 	ThetaFn theta;
 	const char* name;
 };
+// d = 64 / 128: the row / query terms of the bf16x3 fallback form (gemm_terms.hpp); no scan kernel of its own
 const GemmVariant kGemmF32[] = {
-    {64, scan_gemm_f32_kernel<64>, row_norms_kernel<64>, query_theta_kernel<64>, "scan_gemm_f32<64>"},
-    {128, scan_gemm_f32_kernel<128>, row_norms_kernel<128>, query_theta_kernel<128>, "scan_gemm_f32<128>"}};
+    {64, nullptr, row_norms_kernel<64>, query_theta_kernel<64>, "-"},
+    {128, nullptr, row_norms_kernel<128>, query_theta_kernel<128>, "-"}};
 // dims that only the fp16 form covers: a placeholder without kernels (scan == nullptr) keeps the
 // GEMM branch of the level loop alive; without the fp16 form it counts as "no GEMM form"
 const GemmVariant kGemmF16Only[] = {{256, nullptr, nullptr, nullptr, "-"}, {512, nullptr, nullptr, nullptr, "-"},
@@ -414,17 +414,6 @@ struct GemmF16Variant {
 	int tb, wgq, threads, wg_per_cu, lds;  // rows per tile, queries per workgroup, launch geometry
 	int hit_log;                           // scan writes per-wave hit logs (scan_gemm_f16x.hpp) + scatter_log_kernel
 };
-#define F16_V(D)                                                                                   \
-	{D, scan_gemm_f16_kernel<D, false>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>,            \
-	 f16_query_prep_kernel<D>, "scan_gemm_f16<" #D ", false>", kF16TB, F16Geom<D>::WGQ,              \
-	 F16Geom<D>::THREADS, F16Geom<D>::WG_PER_CU, gemm_f16_lds_bytes<D>()}
-// 512 < d <= 960: the k range split over wave pairs (scan_gemm_f16k.hpp)
-#define F16K_V(D)                                                                                  \
-	{D, scan_gemm_f16k_kernel<D, false>, scan_gemm_f16k_kernel<D, true>, sqnorm_kernel<D>,          \
-	 f16_query_prep_kernel<D>, "scan_gemm_f16k<" #D ", false>", F16kGeom<D>::TB, F16kGeom<D>::WGQ,   \
-	 F16kGeom<D>::THREADS, 1, F16kGeom<D>::LDS_BYTES}
-const GemmF16Variant kGemmF16[] = {F16_V(64),   F16_V(128),  F16_V(256), F16_V(512),
-                                   F16K_V(768), F16K_V(832), F16K_V(960)};
 // the 16x16x32 form of the full scan and of the sampled pass (scan_gemm_f16x.hpp)
 #define F16X_V(D)                                                                                  \
 	{D, scan_gemm_f16x_kernel<D, false>, scan_gemm_f16x_kernel<D, true>, sqnorm_kernel<D>,          \
@@ -450,8 +439,6 @@ const GemmF16Variant kGemmF16X[] = {F16X_V(64), F16X_V(128), F16Y_V(256), F16Y_V
 const GemmF16Variant kGemmF16XDbg[] = {{128, scan_gemm_f16x_kernel<128, false, 1>, scan_gemm_f16_kernel<128, true>,
                                         sqnorm_kernel<128>, f16_query_prep_kernel<128>, "scan_gemm_f16x<128, false>",
                                         kF16TB, kF16TQ, kF16Threads, 2, gemm_f16_lds_bytes<128>(), 1}};
-#undef F16_V
-#undef F16K_V
 inline bool f16_choice(long opt) { return opt == 0 || opt == 4 || opt == 6; }
 
 // a handful of queries: the same filter streamed from HBM without the matrix cores
@@ -666,8 +653,10 @@ int ensure_hit_logs(expann_index* h, uint32_t grid, int waves, size_t m, uint32_
                     uint32_t n_qtiles, uint32_t xcd_map, hipStream_t st, uint4** log, uint32_t** log_cnt,
                     uint32_t* log_cap_out) {
 	const uint32_t n_logs = grid * (uint32_t)waves;
+	// four times a wave's average share of the candidate lists (queries sorted by cluster send a wave's
+	// 64 queries to the same row chunk; memory that is never written costs nothing)
 	const uint32_t log_cap = std::max<uint32_t>(
-	    1024, pow2ceil((uint32_t)std::min<size_t>((m * (size_t)cap + n_logs - 1) / n_logs, 1u << 20)));
+	    4096, pow2ceil((uint32_t)std::min<size_t>(4 * ((m * (size_t)cap + n_logs - 1) / n_logs), 1u << 20)));
 	const size_t need = (size_t)n_logs * log_cap * 16;
 	if (need > h->log_bytes || n_logs > h->log_cnt_n) {
 		HIP_TRY(h, hipStreamSynchronize(st));
@@ -824,22 +813,20 @@ struct GemmI8qVariant {
 	void (*scan_w)(GemmI8wParams) = nullptr;
 	int lds_w = 0, threads_w = 0, wg_per_cu_w = 0;
 };
-#define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false>, \
-	scan_gemm_i8q_kernel<DQ, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+#define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false, D>, \
+	scan_gemm_i8q_kernel<DQ, L2F, true, D>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
 	"scan_gemm_i8q<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
 #define GEMM_I8Q(D, MODE, L2F, MN) GEMM_I8Q_P(D, D, MODE, L2F, MN)
 const GemmI8qVariant kGemmI8q[] = {
     GEMM_I8Q(128, kU8L2, true, "U8L2"), GEMM_I8Q(128, kI8L2, true, "I8L2"), GEMM_I8Q(128, kI8IP, false, "I8IP"),
     GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP"),
-    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP"),
-    GEMM_I8Q_P(832, 1024, kU8L2, true, "U8L2"), GEMM_I8Q_P(832, 1024, kI8L2, true, "I8L2"),
-    GEMM_I8Q_P(832, 1024, kI8IP, false, "I8IP"),
-    GEMM_I8Q_P(960, 1024, kU8L2, true, "U8L2"), GEMM_I8Q_P(960, 1024, kI8L2, true, "I8L2"),
-    GEMM_I8Q_P(960, 1024, kI8IP, false, "I8IP")};
+    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP")};
+// (d = 832 / 960 -- rows in 1024-byte slots -- have the 16x16x64 full scan only: kGemmI8x below; their
+// sampled pass is scan_gemm_i8q_kernel<1024, L2F, true, d>)
 // the 16x16x64 form of the full scan for the 8-waves-per-tile geometries (scan_gemm_i8x.hpp); the
 // sampled pass stays scan_gemm_i8q_kernel<DQ, L2F, true>
-#define GEMM_I8X_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8x_kernel<DQ, L2F>, \
-	scan_gemm_i8q_kernel<DQ, L2F, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+#define GEMM_I8X_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8x_kernel<DQ, L2F, D>, \
+	scan_gemm_i8q_kernel<DQ, L2F, true, D>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
 	"scan_gemm_i8x<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
 const GemmI8qVariant kGemmI8x[] = {
     GEMM_I8X_P(768, 768, kU8L2, true, "U8L2"), GEMM_I8X_P(768, 768, kI8L2, true, "I8L2"), GEMM_I8X_P(768, 768, kI8IP, false, "I8IP"),
@@ -1461,15 +1448,16 @@ int SearchPass::choose_kernels() {
 	gvi = force_direct ? nullptr : pick_gemm_i8(h, m);
 	gvb = nullptr;
 	gvf = nullptr;
-	if (h->opt_scan_kernel == 2 && !gv && !gvi)
+	if (h->opt_scan_kernel == 2 && !gvi)
 		return h->fail(EXPANN_ERR_UNSUPPORTED,
-		               "GEMM-form scan (scan_kernel=2): f32 L2 with dim 64/128, or 8-bit L2/IP with dim 128/256/768");
+		               "GEMM-form scan (scan_kernel=2): 8-bit L2/IP with dim 128/256/768 (the fp32-input MFMA form of "
+		               "rounds 1-2 is gone: scan_kernel 3 = bf16x3, 4 = fp16)");
 	if (gvi) {
 		int rc = ensure_bias_i8(h, gvi, st);
 		if (rc != EXPANN_OK)
 			return rc;
 	}
-	if (gv && h->opt_scan_kernel != 2)
+	if (gv)
 		for (const auto& v : kGemmBf16)
 			if (v.d == h->dim)
 				gvb = &v;
@@ -1478,25 +1466,19 @@ int SearchPass::choose_kernels() {
 	// fp16 single-product form: default when available; a search whose queries leave the fp16
 	// range after scaling is redone with the bf16x3 form (no_f16)
 	if (gv && !no_f16 && f16_choice(h->opt_scan_kernel)) {
-		for (const auto& v : kGemmF16)
-			if (v.d == h->dim)
+		const bool dbg = (h->opt_debug & ~16L) != 0;  // (the debug instance exists for d = 128 only)
+		for (const auto& v : kGemmF16X)
+			if (v.d == h->dim && !(dbg && v.d == kGemmF16XDbg[0].d))
 				gvf = &v;
-		if (h->opt_scan_kernel == 6 || (h->opt_scan_kernel == 0 && h->opt_f16x))
-			{
-				const bool dbg = (h->opt_debug & ~16L) != 0;  // (the debug instance exists for d = 128 only)
-				for (const auto& v : kGemmF16X)
-					if (v.d == h->dim && !(dbg && v.d == kGemmF16XDbg[0].d))
-						gvf = &v;
-				if (dbg && kGemmF16XDbg[0].d == h->dim)
-					gvf = &kGemmF16XDbg[0];
-			}
+		if (dbg && kGemmF16XDbg[0].d == h->dim)
+			gvf = &kGemmF16XDbg[0];
 	}
 	if ((h->opt_scan_kernel == 4 || h->opt_scan_kernel == 6) && !gvf && !no_f16)
 		return h->fail(EXPANN_ERR_UNSUPPORTED, "fp16 GEMM-form scan: f32 with dim 64, 128, 256, 512, 768, 832 or 960 only");
 	if (gvf)
 		gvb = nullptr;
-	else if ((h->opt_scan_kernel == 0 && m < 24) || (gv && !gv->scan))
-		gv = nullptr, gvb = nullptr;  // the other GEMM forms only pay from ~24 queries on / do not exist
+	else if ((h->opt_scan_kernel == 0 && m < 24) || !gvb)
+		gv = nullptr, gvb = nullptr;  // without the fp16 form only bf16x3 is left (d = 64 / 128; pays from ~24 queries on)
 	if (gv && !gvf) {
 		int rc = ensure_bnorm(h, gv, gvb != nullptr, st);
 		if (rc != EXPANN_OK)
@@ -1706,9 +1688,7 @@ int SearchPass::run_level(size_t li) {
 			                   2 * kGemmTB * h->dim * sizeof(float), st, bp);
 			kname = gvb->name;
 		} else {
-			hipLaunchKernelGGL(gv->scan, dim3(gchunks * gp.n_qtiles), dim3(kGemmThreads),
-			                   2 * kGemmTB * h->dim * sizeof(float), st, gp);
-			kname = gv->name;
+			return h->fail(EXPANN_ERR_UNSUPPORTED, "no GEMM-form scan kernel for this index");  // (choose_kernels rules it out)
 		}
 		passes = gp.n_qtiles;
 		qt_used = tq_small ? tq_small : tq_wg;  // (launch_scan_f16 reports the tile it used)
@@ -1842,10 +1822,7 @@ int SearchPass::check(int attempt, Next* next) {
 		return EXPANN_OK;
 	// some candidate list overflowed: retry with 4x the capacity
 	h->prof.retries++;
-	if (gvf && gvf->hit_log)  // (or a hit log / queue of the 16x16x32 form: the direct appends have no such limit)
-		for (const auto& v : kGemmF16)
-			if (v.d == h->dim)
-				gvf = &v;
+	// (a hit log of the 16x16x32 form that overflowed counts like a list: the logs grow with the lists)
 	if ((cap >= kMaxCap || attempt >= 3) && (gv || gvi) && h->opt_scan_kernel == 0) {
 		// the GEMM forms cannot break exact ties by row number; the direct scan can
 		force_direct = true;
@@ -2067,17 +2044,6 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		delete h;
 		return EXPANN_ERR_HIP;
 	}
-	for (const auto& v : kGemmF16)
-		if (v.d == dim)
-			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) !=
-			        hipSuccess ||
-			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) !=
-			        hipSuccess) {
-				g_create_error = "hipFuncSetAttribute(scan_gemm_f16_kernel) failed";
-				hipStreamDestroy(h->stream);
-				delete h;
-				return EXPANN_ERR_HIP;
-			}
 	for (const auto& v : kGemmF16X)
 		if (v.d == dim &&  // (the sampled pass is launched with the scan's LDS size, never less than its own)
 		    (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess ||
@@ -2128,15 +2094,6 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
 			                        2 * kGemmTB * dim * (int)sizeof(float)) != hipSuccess) {
 				g_create_error = "hipFuncSetAttribute(scan_gemm_bf16x3_kernel) failed";
-				hipStreamDestroy(h->stream);
-				delete h;
-				return EXPANN_ERR_HIP;
-			}
-	for (const auto& v : kGemmF32)
-		if (v.d == dim)
-			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        2 * kGemmTB * dim * (int)sizeof(float)) != hipSuccess) {
-				g_create_error = "hipFuncSetAttribute(scan_gemm_f32_kernel) failed";
 				hipStreamDestroy(h->stream);
 				delete h;
 				return EXPANN_ERR_HIP;
@@ -2208,7 +2165,7 @@ int expann_build(expann_index* h) {
 	// the fp16 copy every fp32 search of a built dim filters through: made here, inside the
 	// reference's timed build span (basic_bench.h:63-71), not inside the first query
 	if (h->dtype == EXPANN_DTYPE_F32 && h->n >= 4096 && h->opt_scan_kernel == 0)
-		for (const auto& v : kGemmF16)
+		for (const auto& v : kGemmF16X)
 			if (v.d == h->dim) {
 				const int rc = ensure_f16(h, &v, h->stream);
 				if (rc != EXPANN_OK)

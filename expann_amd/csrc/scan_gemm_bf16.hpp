@@ -1,4 +1,4 @@
-// scan_gemm_bf16.hpp -- the GEMM-form fp32 L2 candidate filter (scan_gemm_f32.hpp) on the bf16
+// scan_gemm_bf16.hpp -- the GEMM-form fp32 L2 candidate filter (round 1-2's fp32-input MFMA form) on the bf16
 // matrix cores with a 3-term split: every fp32 value x is stored as two bf16 numbers
 //      hi = bf16(x),   lo = bf16(x - hi)            (|x - hi - lo| <= 2^-18 |x|)
 // and the inner product is evaluated as  q.b ~= qh.bh + qh.bl + ql.bh  with
@@ -21,10 +21,10 @@
 // sharing one A fragment pair); the A fragments (d/16 k-steps x {hi,lo} x 4 VGPRs) stay in
 // registers.  A lane's k-slice of a part
 // is dims [d/2*h, d/2*(h+1)) (h = lane>>5), 8 dims per MFMA.  LDS staging and the source-side XOR
-// swizzle are those of scan_gemm_f32.hpp.
+// swizzle are those of rounds 1-2's fp32-input form.
 #pragma once
 #include "common.hpp"
-#include "scan_gemm_f32.hpp"
+#include "gemm_terms.hpp"
 
 namespace expann {
 

@@ -347,11 +347,11 @@ static_assert(gemm_f16_lds_bytes<64>() * 3 <= 160 * 1024 &&
               "LDS budget per CU");
 
 template <int D, bool SAMPLE>
-__global__ __launch_bounds__(F16Geom<D>::THREADS, (F16Geom<D>::TH_LDS && !SAMPLE) ? 3 : 2) void
-scan_gemm_f16_kernel(GemmF16Params p) {
+__global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
+	static_assert(SAMPLE, "round 3: the 32 x 32 x 16 stream serves the sampled pass only (d = 256 / 512); the full scans are scan_gemm_f16x / f16y");
 	static_assert(D == 64 || D == 128 || D == 256 || D == 512, "built for d = 64, 128, 256, 512");
 	using G = F16Geom<D>;
-	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
+	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ;
 	constexpr bool NATURAL = G::NATURAL;
 	constexpr int ROWB = D * 2;      // bytes per fp16 row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
@@ -386,22 +386,6 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 
 	// LDS map
 	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
-	struct QEntry {
-		float acc[16];
-		float bn;
-		uint32_t row;
-		uint32_t qrow0;  // query of accumulator register 0; register r is + (r & 3) + 8 (r >> 2)
-		uint32_t pad;
-	};
-	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
-	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * WAVES * 256) + wave * QCAP;
-	float* const thq =
-	    reinterpret_cast<float*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
-	constexpr bool THL = G::TH_LDS && !SAMPLE;
-	// (THL) accumulator start values by (wave, lane half): 16 per query tile, read back as broadcasts
-	float* const thl = reinterpret_cast<float*>(fills + 16) + (wave * 2 + h) * (TQW * 16);
-
 	f16x8 a[TQW][KS];
 #pragma unroll
 	for (int tq = 0; tq < TQW; ++tq) {
@@ -414,25 +398,13 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 		for (int s = 0; s < KS; ++s)
 			a[tq][s] = src[NATURAL ? 2 * s + h : h * KS + s];
 	}
-	// accumulator start values: theta' of the query each accumulator register belongs to
-	// (SAMPLE: they start at zero, and th holds the running class maxima of g instead)
+	// the accumulators start at zero; th holds the running class maxima of g
 	f32x16 th[TQW];
 #pragma unroll
 	for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
-		for (int reg = 0; reg < 16; ++reg) {
-			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			th[tq][reg] = (qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff();
-		}
-	if (!SAMPLE && tid < WGQ)
-		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
-	if (THL && r31 == 0) {
-#pragma unroll
-		for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-			for (int reg = 0; reg < 16; ++reg)
-				thl[tq * 16 + reg] = th[tq][reg];
-	}
+		for (int reg = 0; reg < 16; ++reg)
+			th[tq][reg] = -__builtin_inff();
 	// the query fragments and thresholds are in registers before the first stage load is issued:
 	// a later wait for them would be a vmcnt(0) inside the loop and drain the prefetch queue
 #pragma unroll
@@ -440,8 +412,7 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
-		if (!THL)
-			asm volatile("" : "+v"(th[tq]));
+		asm volatile("" : "+v"(th[tq]));
 	}
 	// per-lane LDS offset of k-step s (row r31 of the first column tile); the second column tile
 	// is 32 rows further, where the swizzle term is the same
@@ -506,104 +477,10 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 		bnv[1] = slot[32 + r31];
 	};
 
-	// Candidates: a lane whose 16 accumulators of a 32x32 tile hold at least one hit (about a
-	// third of all tiles do, at ~32k candidates per query) appends the raw 16-vector, its bn', row
-	// and first query to its WAVE's queue in LDS: the slot comes from a wave-uniform counter and
-	// the lane's rank in the ballot, so the hot loop has no atomic and no per-register branch.
-	// Every kF16FlushEvery steps the waves look at each other's fills and, if one is half full,
-	// each empties its own queue: 16 lanes per entry redo the compare and push the hits to the
-	// global per-query lists, a batch of atomics in flight at a time.
-	uint32_t wfill = 0;  // wave-uniform
-	auto push_global = [&](uint32_t qi, uint64_t key) {
-		const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
-		if (slot < p.cap)
-			p.cand[(size_t)qi * p.cap + slot] = key;
-	};
-	// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
-	auto flush_own = [&]() {
-		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		constexpr int R = D >= 512 ? 4 : 8;
-		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
-			bool hit[R];
-			uint32_t qi[R], slot[R];
-			uint64_t key[R];
-#pragma unroll
-			for (int j = 0; j < R; ++j) {
-				const uint32_t i = base + j * 64 + lane;
-				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
-				const uint32_t reg = i & 15;
-				const float c = e.acc[reg], bn = e.bn;
-				hit[j] = i < n * 16 && c >= bn;
-				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
-				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (WGQ - 1)]) * p.two_inv_s2, e.row);
-			}
-			if (p.debug & 64)
-				continue;  // (ablation: the queue is emptied, nothing reaches the lists)
-#pragma unroll
-			for (int j = 0; j < R; ++j)
-				slot[j] = hit[j] ? atomicAdd(&p.cand_cnt[qi[j]], 1u) : 0xFFFFFFFFu;
-#pragma unroll
-			for (int j = 0; j < R; ++j)
-				if (hit[j] && slot[j] < p.cap)
-					p.cand[(size_t)qi[j] * p.cap + slot[j]] = key[j];
-		}
-		wfill = 0;
-	};
-	auto epilogue = [&](const f32x16 (&accs)[TQW][2], uint32_t row0, const float (&bnv)[2]) {
-#pragma unroll
-		for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-			for (int tc = 0; tc < 2; ++tc) {
-				const f32x16& c = accs[tq][tc];
-				const float bn = bnv[tc];
-				float m0 = max3f(c[0], c[1], c[2]);
-				float m1 = max3f(c[3], c[4], c[5]);
-				float m2 = max3f(c[6], c[7], c[8]);
-				float m3 = max3f(c[9], c[10], c[11]);
-				float m4 = max3f(c[12], c[13], c[14]);
-				m0 = max3f(m0, m1, c[15]);
-				m2 = max3f(m2, m3, m4);
-				m0 = __builtin_fmaxf(m0, m2);
-				const unsigned long long mask = __builtin_amdgcn_ballot_w64(m0 >= bn);
-				if (mask != 0 && !(p.debug & 8)) {
-					uint32_t qrow0 = q0 + tq * 32 + 4 * h;  // rare path: arithmetic stays in here
-					asm volatile("" : "+v"(qrow0));
-					const uint32_t brow = row0 + tc * 32 + r31;
-					const uint32_t slot =
-					    wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-					                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-					if (m0 >= bn) {
-						if (slot < (uint32_t)QCAP) {
-							QEntry& e = queue[slot];
-#pragma unroll
-							for (int reg = 0; reg < 16; ++reg)
-								e.acc[reg] = c[reg];
-							e.bn = bn;
-							e.row = brow;
-							e.qrow0 = qrow0;
-						} else {  // queue full (pathological thresholds): straight to the lists
-#pragma unroll 1
-							for (int reg = 0; reg < 16; ++reg) {
-								float cr = c[0];
-#pragma unroll
-								for (int j = 1; j < 16; ++j)
-									cr = reg == j ? c[j] : cr;
-								if (cr >= bn) {
-									const uint32_t qi = qrow0 + (reg & 3) + 8 * (reg >> 2);
-									push_global(qi, make_key(((bn - cr) + p.theta[qi]) * p.two_inv_s2, brow));
-								}
-							}
-						}
-					}
-					wfill += (uint32_t)__builtin_popcountll(mask);
-				}
-			}
-	};
-
 #pragma unroll
 	for (int i = 0; i < PF; ++i)
 		stage(t0 + i, i);
-	wait_vm_then_barrier<(PF - 1) * LOADS>();  // tile t0 landed, thq visible
+	wait_vm_then_barrier<(PF - 1) * LOADS>();  // tile t0 landed
 
 	f32x16 acc[TQW][2];
 	f32x16 zero16;
@@ -612,7 +489,6 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 		zero16[e] = 0.0f;
 	float bnv[2];
 	int buf = 0, pbuf = PF;  // pbuf: buffer that tile t+PF goes to (= the one tile t-1 used)
-	uint32_t since_look = 0;
 	for (uint32_t t = t0; t < t1; ++t) {
 		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int tc, int s) -> f16x8 {
@@ -633,86 +509,45 @@ scan_gemm_f16_kernel(GemmF16Params p) {
 			fb[s][1] = frag(1, s);
 		}
 		read_bn(bnv, buf);
-		// the MFMA phase outranks the other workgroup's epilogue / flush on this SIMD (+4 %)
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s) {
 			if (s + FD < KS) {  // FD k-steps ahead: a wait for k-step s+1 never meets a fresh request
-				if (p.debug & 32) {
-					fb[s + FD][0] = fb[0][0];
-					fb[s + FD][1] = fb[0][1];
-				} else {
-					fb[s + FD][0] = frag(0, s + FD);
-					fb[s + FD][1] = frag(1, s + FD);
-				}
+				fb[s + FD][0] = frag(0, s + FD);
+				fb[s + FD][1] = frag(1, s + FD);
 			}
 #pragma unroll
 			for (int tq = 0; tq < TQW; ++tq) {
-				if (THL && s == 0) {
-					// start values straight from LDS into the first accumulator, which then seeds
-					// both column tiles (second one first: the first is overwritten in place)
-					acc[tq][0] = *reinterpret_cast<const f32x16*>(thl + tq * 16);
-					acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][1], acc[tq][0], 0, 0, 0);
-					acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][0], acc[tq][0], 0, 0, 0);
-					continue;
-				}
-				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-				    a[tq][s], fb[s][0], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][0], 0, 0, 0);
-				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-				    a[tq][s], fb[s][1], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
+				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][0], s == 0 ? zero16 : acc[tq][0], 0, 0, 0);
+				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][1], s == 0 ? zero16 : acc[tq][1], 0, 0, 0);
 			}
-			if (s < LOADS && !(p.debug & 2))
+			if (s < LOADS)
 				stage_piece(stb, srow0, pbuf, s);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		__builtin_amdgcn_s_setprio(0);
-		if (SAMPLE) {
-			// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
-			// never wins a max
-#pragma unroll
-			for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-				for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-					for (int reg = 0; reg < 16; ++reg)
-						th[tq][reg] = __builtin_fmaxf(th[tq][reg], acc[tq][tc][reg] - bnv[tc]);
-			wait_vm_then_barrier<(PF - 1) * LOADS>();
-		} else {
-			if (!(p.debug & 4))
-				epilogue(acc, tile_row0(t), bnv);
-			// a queue about to overflow is emptied at once (dense hits: few workgroups, loose
-			// thresholds); the slow straight-to-the-lists path stays a last resort
-			if (wfill >= (uint32_t)QCAP * 3 / 4)
-				flush_own();
-			const bool look = ++since_look == kF16FlushEvery;
-			if (look && lane == 0)
-				fills[wave] = wfill;
-			// tile t+1 must have landed; the stages of tiles t+2 .. t+PF may stay in flight
-			if (!(p.debug & 1))
-				wait_vm_then_barrier<(PF - 1) * LOADS>();
-			if (look) {
-				since_look = 0;
-				const uint32_t f = fills[lane & (WAVES - 1)];
-				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
-					flush_own();
-			}
-		}
-		pbuf = buf;
-		buf = buf + 1 == NBUF ? 0 : buf + 1;
-	}
-	if (SAMPLE) {
+		// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
+		// never wins a max
 #pragma unroll
 		for (int tq = 0; tq < TQW; ++tq)
 #pragma unroll
-			for (int reg = 0; reg < 16; ++reg) {
-				const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-				if (qi < p.m)
-					p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[tq][reg];
-			}
-	} else {
-		flush_own();
+			for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+				for (int reg = 0; reg < 16; ++reg)
+					th[tq][reg] = __builtin_fmaxf(th[tq][reg], acc[tq][tc][reg] - bnv[tc]);
+		wait_vm_then_barrier<(PF - 1) * LOADS>();
+		pbuf = buf;
+		buf = buf + 1 == NBUF ? 0 : buf + 1;
 	}
+#pragma unroll
+	for (int tq = 0; tq < TQW; ++tq)
+#pragma unroll
+		for (int reg = 0; reg < 16; ++reg) {
+			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+			if (qi < p.m)
+				p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[tq][reg];
+		}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tiles: LDS must outlive them
 	if (p.clk && blockIdx.x == 0 && tid == 0) {
 		p.clk[0] = clock64() - clk0;

@@ -52,8 +52,9 @@ template <int D> struct F16kGeom {
 template <int D, bool SAMPLE>
 __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p) {
 	static_assert(D == 768 || D == 832 || D == 960, "built for d = 768, 832, 960");
+	static_assert(SAMPLE, "round 3: the 32 x 32 x 16 stream serves the sampled pass only; the full scan is scan_gemm_f16kx");
 	using G = F16kGeom<D>;
-	constexpr int THREADS = G::THREADS, WGQ = G::WGQ, QCAP = G::QCAP, TB = G::TB;
+	constexpr int THREADS = G::THREADS, WGQ = G::WGQ, TB = G::TB;
 	constexpr int ROWB = G::ROWB, CH = G::CH, KSA = G::KSA, KSB = G::KSB, NA = G::NA, SWG = G::SWG;
 	constexpr int TILE_BYTES = G::TILE_BYTES;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -83,18 +84,6 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 	// LDS map
 	unsigned char* const bn_slots = smem + G::NBUF * TILE_BYTES;
 	unsigned char* const xch = bn_slots + G::NBUF * 256;
-	struct QEntry {
-		float acc[16];
-		float bn;
-		uint32_t row;
-		uint32_t qrow0;  // query of accumulator register 0; register r is + (r & 3) + 8 (r >> 2)
-		uint32_t pad;
-	};
-	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
-	QEntry* const queue = reinterpret_cast<QEntry*>(xch + G::XCH_BYTES) + qg * QCAP;  // (kh = 0 waves)
-	float* const thq = reinterpret_cast<float*>(xch + G::XCH_BYTES + G::PAIRS * QCAP * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
-
 	// this wave's k-steps: kh * KSA + s
 	f16x8 a[KSB];
 	{
@@ -107,18 +96,11 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 		for (int s = 0; s < KSB; ++s)
 			a[s] = src[2 * s + h];  // (kh = 0: the last KSB - KSA are loaded but never multiplied)
 	}
-	// accumulator start values: theta' with the first k-half, zero with the second; SAMPLE: zero, and
-	// th holds the running class maxima of g
+	// the accumulators start at zero; th holds the running class maxima of g
 	f32x16 th;
 #pragma unroll
-	for (int reg = 0; reg < 16; ++reg) {
-		const uint32_t qi = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-		th[reg] = SAMPLE ? -__builtin_inff() : (kh == 0 ? (qi < p.m ? p.theta[qi] : -__builtin_inff()) : 0.0f);
-	}
-	if (!SAMPLE && tid < WGQ)
-		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
-	if (tid < 8)
-		fills[tid] = 0;
+	for (int reg = 0; reg < 16; ++reg)
+		th[reg] = -__builtin_inff();
 #pragma unroll
 	for (int s = 0; s < KSB; ++s)
 		asm volatile("" : "+v"(a[s]));  // in registers before the first stage load (see scan_gemm_f16_kernel)
@@ -172,82 +154,6 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 		return (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB;
 	};
 
-	// candidate queue of the kh = 0 wave (scan_gemm_f16_kernel's, one column tile)
-	uint32_t wfill = 0;  // wave-uniform
-	auto push_global = [&](uint32_t qi, uint64_t key) {
-		const uint32_t slot = atomicAdd(&p.cand_cnt[qi], 1u);
-		if (slot < p.cap)
-			p.cand[(size_t)qi * p.cap + slot] = key;
-	};
-	auto flush_own = [&]() {
-		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		constexpr int R = 4;
-		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
-			bool hit[R];
-			uint32_t qi[R], slot[R];
-			uint64_t key[R];
-#pragma unroll
-			for (int j = 0; j < R; ++j) {
-				const uint32_t i = base + j * 64 + lane;
-				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
-				const uint32_t reg = i & 15;
-				const float c = e.acc[reg], bn = e.bn;
-				hit[j] = i < n * 16 && c >= bn;
-				qi[j] = e.qrow0 + (reg & 3) + 8 * (reg >> 2);
-				key[j] = make_key(((bn - c) + thq[(qi[j] - wg_q0) & (WGQ - 1)]) * p.two_inv_s2, e.row);
-			}
-#pragma unroll
-			for (int j = 0; j < R; ++j)
-				slot[j] = hit[j] ? atomicAdd(&p.cand_cnt[qi[j]], 1u) : 0xFFFFFFFFu;
-#pragma unroll
-			for (int j = 0; j < R; ++j)
-				if (hit[j] && slot[j] < p.cap)
-					p.cand[(size_t)qi[j] * p.cap + slot[j]] = key[j];
-		}
-		wfill = 0;
-	};
-	auto epilogue = [&](const f32x16& c, uint32_t row0, float bn) {
-		float m0 = max3f(c[0], c[1], c[2]);
-		float m1 = max3f(c[3], c[4], c[5]);
-		float m2 = max3f(c[6], c[7], c[8]);
-		float m3 = max3f(c[9], c[10], c[11]);
-		float m4 = max3f(c[12], c[13], c[14]);
-		m0 = max3f(m0, m1, c[15]);
-		m2 = max3f(m2, m3, m4);
-		m0 = __builtin_fmaxf(m0, m2);
-		const unsigned long long mask = __builtin_amdgcn_ballot_w64(m0 >= bn);
-		if (mask != 0 && !(p.debug & 8)) {
-			uint32_t qrow0 = q0 + 4 * h;
-			asm volatile("" : "+v"(qrow0));
-			const uint32_t brow = row0 + r31;
-			const uint32_t slot = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-			                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-			if (m0 >= bn) {
-				if (slot < (uint32_t)QCAP) {
-					QEntry& e = queue[slot];
-#pragma unroll
-					for (int reg = 0; reg < 16; ++reg)
-						e.acc[reg] = c[reg];
-					e.bn = bn;
-					e.row = brow;
-					e.qrow0 = qrow0;
-				} else {  // queue full (pathological thresholds): straight to the lists
-#pragma unroll 1
-					for (int reg = 0; reg < 16; ++reg) {
-						float cr = c[0];
-#pragma unroll
-						for (int j = 1; j < 16; ++j)
-							cr = reg == j ? c[j] : cr;
-						if (cr >= bn) {
-							const uint32_t qi = qrow0 + (reg & 3) + 8 * (reg >> 2);
-							push_global(qi, make_key(((bn - cr) + p.theta[qi]) * p.two_inv_s2, brow));
-						}
-					}
-				}
-			}
-			wfill += (uint32_t)__builtin_popcountll(mask);
-		}
-	};
 
 	{
 		uint32_t row0;
@@ -256,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 		for (int i = 0; i < LOADS; ++i)
 			stage_piece(tb, row0, 0, i);
 	}
-	wait_vm_then_barrier<0>();  // tile t0 landed, thq / fills visible
+	wait_vm_then_barrier<0>();  // tile t0 landed
 
 	f32x16 zero16;
 #pragma unroll
@@ -264,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 		zero16[e] = 0.0f;
 	f32x16 acc;
 	int buf = 0;
-	uint32_t par = 0, since_look = 0;
+	uint32_t par = 0;
 	for (uint32_t t = t0; t < t1; ++t) {
 		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
 		auto frag = [&](int s) -> f16x8 {
@@ -287,8 +193,8 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 				fb[s + FD] = frag(s + FD);
 			else if (s + FD < KSB && kh)
 				fb[s + FD] = frag(s + FD);
-			acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], fb[s], s == 0 ? (SAMPLE ? zero16 : th) : acc, 0, 0, 0);
-			if (s < LOADS && !(p.debug & 2))
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], fb[s], s == 0 ? zero16 : acc, 0, 0, 0);
+			if (s < LOADS)
 				stage_piece(stb, srow0, buf ^ 1, s);
 			__builtin_amdgcn_sched_barrier(0);
 		}
@@ -319,40 +225,19 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16k_kernel(GemmF16Params p)
 				acc[4 * j + 2] += v.z;
 				acc[4 * j + 3] += v.w;
 			}
-			if (SAMPLE) {
 #pragma unroll
-				for (int reg = 0; reg < 16; ++reg)
-					th[reg] = __builtin_fmaxf(th[reg], acc[reg] - bnv);
-			} else {
-				// queue fills posted at the previous step are visible after this step's barrier: if a
-				// queue of the workgroup is half full, every wave empties its own now
-				if (since_look == kF16FlushEvery) {
-					since_look = 0;
-					const uint32_t f = fills[lane & 3];
-					if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
-						flush_own();
-				}
-				if (!(p.debug & 4))
-					epilogue(acc, tile_row0(t), bnv);
-				if (wfill >= (uint32_t)QCAP * 3 / 4)
-					flush_own();
-				if (++since_look == kF16FlushEvery && lane == 0)
-					fills[qg] = wfill;
-			}
+			for (int reg = 0; reg < 16; ++reg)
+				th[reg] = __builtin_fmaxf(th[reg], acc[reg] - bnv);
 		}
 		buf ^= 1;
 		par ^= 1;
 	}
 	if (!kh) {
-		if (SAMPLE) {
 #pragma unroll
-			for (int reg = 0; reg < 16; ++reg) {
-				const uint32_t qi = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-				if (qi < p.m)
-					p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[reg];
-			}
-		} else {
-			flush_own();
+		for (int reg = 0; reg < 16; ++reg) {
+			const uint32_t qi = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+			if (qi < p.m)
+				p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[reg];
 		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tile: LDS must outlive it

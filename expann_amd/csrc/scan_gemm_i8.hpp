@@ -2,7 +2,7 @@
 // matrix cores (v_mfma_i32_32x32x32_i8), BASELINE config C5 (int8 inner product) and the int8 /
 // uint8 L2 forms.
 //
-// Integer arithmetic is exact, so unlike the fp32 GEMM form (scan_gemm_f32.hpp) no slack and
+// Integer arithmetic is exact, so unlike the fp32 GEMM form (round 1-2's fp32-input MFMA form) no slack and
 // no re-rank are needed: the expanded identity  sum(a-b)^2 = sum a^2 + sum b^2 - 2 sum ab  holds
 // exactly in wrapping 32-bit integers, and the candidates leave this kernel with their final
 // scores.  uint8 rows (src/antitopo_engine.h:38-61) are mapped to int8 by subtracting 128 from
@@ -20,7 +20,7 @@
 // the source address exactly like the fp32 kernel.
 #pragma once
 #include "common.hpp"
-#include "scan_gemm_f32.hpp"
+#include "gemm_terms.hpp"
 #include "scan_int8.hpp"
 
 namespace expann {

@@ -113,16 +113,21 @@ static_assert(gemm_i8q_lds_bytes<768>() <= 160 * 1024 && gemm_i8q_lds_bytes<1024
                   gemm_i8q_lds_bytes<128>() * 3 <= 160 * 1024,
               "LDS budget per CU");
 
-template <int D, bool L2FORM, bool SAMPLE>
+// DR = bytes of a row that hold data (d = 832 / 960 rows live in 1024-byte slots, zero-padded on both
+// sides of the product): the k-steps behind them multiply zeros and are left out -- 26 / 30 of 32
+// k-steps, and as many query fragments less in registers (at D = DR = 1024 the kernel spilled)
+template <int D, bool L2FORM, bool SAMPLE, int DR = D>
 __global__ __launch_bounds__(I8qGeom<D>::THREADS, (I8qGeom<D>::TH_LDS && !SAMPLE) ? 3 : 2) void
 scan_gemm_i8q_kernel(GemmI8qParams p) {
 	static_assert(D == 128 || D == 256 || D == 768 || D == 1024, "built for d = 128, 256, 768, 1024");
+	static_assert(DR == D || (I8qGeom<D>::NATURAL && DR < D && DR % 64 == 0), "padded rows: natural chunk order");
 	using G = I8qGeom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ, QCAP = G::QCAP;
 	constexpr bool NATURAL = G::NATURAL;
 	constexpr int ROWB = D;          // bytes per row
 	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
-	constexpr int KS = D / 32;       // MFMA k-steps
+	constexpr int KS = D / 32;       // MFMA k-steps of a row slot
+	constexpr int KR = (DR + 31) / 32;  // ... that hold data
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
@@ -169,7 +174,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 
 	constexpr int kNever = -2147483647 - 1;
 	// query fragments; lane half h of k-step s holds chunk 2s + h (natural) or h*KS + s
-	i32x4 a[TQW][KS];
+	i32x4 a[TQW][KR];
 #pragma unroll
 	for (int tq = 0; tq < TQW; ++tq) {
 		uint32_t qi = q0 + tq * 32 + r31;
@@ -178,7 +183,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 		const i32x4* src =
 		    reinterpret_cast<const i32x4*>((const unsigned char*)p.queries + (size_t)qi * ROWB);
 #pragma unroll
-		for (int s = 0; s < KS; ++s)
+		for (int s = 0; s < KR; ++s)
 			a[tq][s] = src[NATURAL ? 2 * s + h : h * KS + s];
 	}
 	// accumulator start values -g_k (SAMPLE: zero starts; th holds the running class maxima)
@@ -203,7 +208,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 #pragma unroll
 	for (int tq = 0; tq < TQW; ++tq) {
 #pragma unroll
-		for (int s = 0; s < KS; ++s)
+		for (int s = 0; s < KR; ++s)
 			asm volatile("" : "+v"(a[tq][s]));
 		if (!THL)
 			asm volatile("" : "+v"(th[tq]));
@@ -375,7 +380,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 		};
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
-		i32x4 fb[KS][2];
+		i32x4 fb[KR][2];
 		fb[0][0] = frag(0, 0);
 		fb[0][1] = frag(1, 0);
 		fb[1][0] = frag(0, 1);
@@ -384,8 +389,8 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 		__builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the other workgroup's epilogue / flush
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int s = 0; s < KS; ++s) {
-			if (s + 2 < KS) {
+		for (int s = 0; s < KR; ++s) {
+			if (s + 2 < KR) {
 				fb[s + 2][0] = frag(0, s + 2);
 				fb[s + 2][1] = frag(1, s + 2);
 			}
@@ -405,7 +410,7 @@ scan_gemm_i8q_kernel(GemmI8qParams p) {
 				    a[tq][s], fb[s][1], s == 0 ? (SAMPLE ? zero16 : th[tq]) : acc[tq][1], 0, 0, 0);
 			}
 			// the stage loads of tile t+PF go out between the MFMAs
-			constexpr int PER = (LOADS + KS - 1) / KS;
+			constexpr int PER = (LOADS + KR - 1) / KR;
 #pragma unroll
 			for (int j = 0; j < PER; ++j)
 				if (s * PER + j < LOADS)

@@ -18,15 +18,17 @@
 
 namespace expann {
 
-template <int D, bool L2FORM>
+// DR: bytes of a row slot that hold data (scan_gemm_i8q_kernel): 13 / 15 of the 16 k-steps at d = 832 / 960
+template <int D, bool L2FORM, int DR = D>
 __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(GemmI8qParams p) {
 	static_assert(D == 768 || D == 1024, "the 8-waves-per-tile geometry of scan_gemm_i8q.hpp");
+	static_assert(DR <= D && DR % 64 == 0, "whole k-steps of data");
 	using G = I8qGeom<D>;
 	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, WGQ = G::WGQ, QCAP = G::QCAP;
 	static_assert(G::TQW == 1 && G::NATURAL && !G::TH_LDS, "32 queries per wave, natural chunk order");
 	constexpr int ROWB = D;
 	constexpr int CH = ROWB / 16;
-	constexpr int KS = D / 64;  // MFMA k-steps of 64 bytes
+	constexpr int KS = DR / 64;  // MFMA k-steps of 64 bytes that hold data
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int NBUF = G::NBUF, PF = NBUF - 1;
 	static_assert(ROWB % 256 == 0, "rows start on an LDS bank row: the XOR swizzle is (row & 15)");
@@ -108,17 +110,30 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	constexpr int N_STAGE = kF16TB * CH / THREADS;
 	static_assert(kF16TB * CH % THREADS == 0, "whole staging rounds");
 	constexpr int LOADS = N_STAGE + 1;
-	uint32_t soff[N_STAGE];
+	// source offset of this thread's piece i of a tile (chunk S = i THREADS + tid: row S / CH, chunk S %
+	// CH, swizzled).  1024-byte slots: a round covers 8 rows, so rounds of equal parity see the same
+	// swizzle term and two registers + a multiple of 16 rows serve all of them (8 registers fewer: with
+	// them the d = 960 instance spilled).
+	constexpr bool SOFF2 = CH == 64 && THREADS == 512;
+	uint32_t soff[SOFF2 ? 2 : N_STAGE];
 #pragma unroll
-	for (int i = 0; i < N_STAGE; ++i) {
+	for (int i = 0; i < (SOFF2 ? 2 : N_STAGE); ++i) {
 		const uint32_t S = i * THREADS + tid;
 		const uint32_t r = S / CH, pc = S % CH;
 		soff[i] = r * ROWB + ((pc ^ (r & 15)) * 16);
 	}
+	auto soff_of = [&](int i) -> uint32_t {
+		if (SOFF2) {
+			uint32_t b = soff[i & 1];
+			asm volatile("" : "+v"(b));  // (kept opaque: hipcc would hoist the eight sums out of the tile loop again)
+			return b + (uint32_t)(i >> 1) * 16u * ROWB;
+		}
+		return soff[SOFF2 ? 0 : i];
+	};
 	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
 		if (i < N_STAGE) {
 			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + soff[i < N_STAGE ? i : 0]),
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + soff_of(i < N_STAGE ? i : 0)),
 			                                 (__attribute__((address_space(3))) void*)(dst0 + i * THREADS * 16), 16, 0, 0);
 		} else {
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bp + row0 + lane),
