@@ -102,6 +102,7 @@ struct expann_index {
 	DevPtr<int> d_bp_i8q;            // [n padded] floor(bias/2), scan_gemm_i8q.hpp
 	DevPtr<void> d_log;              // per-wave hit logs of scan_gemm_f16x ([n_logs][log_cap] x 16 B)
 	DevPtr<uint32_t> d_log_cnt;      // [n_logs]
+	DevPtr<uint32_t> d_work_ctr;     // [8][16]: per-XCD item counters of the persistent scan launch
 	size_t log_bytes = 0, log_cnt_n = 0;
 	struct {                         // scatter_log_kernel of the scan just launched (run after its timing event)
 		uint32_t n_logs = 0, log_cap = 0, cap = 0, n_chunks = 0, n_qtiles = 0, xcd_map = 0, m = 0;
@@ -140,6 +141,7 @@ struct expann_index {
 	                                 // 1000 contiguous clusters); on iid rows the two differ by < 1 %
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_tail_chunks = 1;        // scan_gemm_f16x: the last round's row chunks three times finer (pick_tail_chunks)
+	long opt_persist = 1;            // scan_gemm_f16x: resident workgroups pull (query tile, row chunk) items per XCD
 	long opt_i8w = 1;                // 8-bit rows, d = 128 / 256: scan_gemm_i8w.hpp (16x16x64, f16x's step, hit logs)
 	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
 	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
@@ -1361,7 +1363,18 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 				return lrc;
 			fp.lost = h->d_overflow;
 		}
-		hipLaunchKernelGGL(gvf->scan, dim3(grid), dim3((uint32_t)gvf->threads), gvf->lds, st, fp);
+		uint32_t launch_grid = grid;
+		const uint32_t resident = (uint32_t)gvf->wg_per_cu * (uint32_t)cus;
+		if (gvf->hit_log && gvf->d == 128 && h->opt_persist && grid > resident) {  // (built into the d = 128 instance)
+			// persistent launch: what is resident pulls the `grid` items from per-XCD counters
+			if (!h->d_work_ctr)
+				HIP_TRY(h, hipMalloc(&h->d_work_ctr, sizeof(uint32_t) * 8 * 16));
+			HIP_TRY(h, hipMemsetAsync(h->d_work_ctr, 0, sizeof(uint32_t) * 8 * 16, st));
+			fp.work_ctr = h->d_work_ctr;
+			fp.n_items = grid;
+			launch_grid = resident;
+		}
+		hipLaunchKernelGGL(gvf->scan, dim3(launch_grid), dim3((uint32_t)gvf->threads), gvf->lds, st, fp);
 		*kname = gvf->name;
 	}
 	*n_qtiles = fp.n_qtiles;
@@ -2030,6 +2043,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		h->opt_i8w = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_TAIL_CHUNKS"))
 		h->opt_tail_chunks = std::atol(e);
+	if (const char* e = std::getenv("EXPANN_PERSIST"))
+		h->opt_persist = std::atol(e);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
 		g_create_error = "hipSetDevice/hipStreamCreate failed";
 		delete h;
@@ -2534,6 +2549,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_i8w = value;
 	else if (!std::strcmp(name, "tail_chunks"))
 		h->opt_tail_chunks = value;
+	else if (!std::strcmp(name, "persist"))
+		h->opt_persist = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

@@ -229,6 +229,10 @@ struct GemmF16Params {
 	uint32_t* log_cnt;
 	uint32_t log_cap;
 	uint32_t* lost;
+	// scan_gemm_f16x_kernel only: persistent launch -- work_ctr[16 * x] = the next item of XCD x's queue
+	// (zero at launch, one cache line each), n_items = the plain launch's grid; nullptr = plain launch
+	uint32_t* work_ctr;
+	uint32_t n_items;
 };
 
 // Per-wave hit logs -> per-query candidate lists.  The 64 queries of (query tile, wave w) receive

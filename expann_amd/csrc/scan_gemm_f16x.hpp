@@ -60,12 +60,20 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int l15 = lane & 15, lq = lane >> 4;
-	uint32_t qtile = blockIdx.x % p.n_qtiles;
-	uint32_t chunk = blockIdx.x / p.n_qtiles;
+	// One work item = what a workgroup of the plain launch does: (query tile, row chunk) number `bid` of
+	// n_items.  Plain launch: bid = blockIdx.x.  Persistent launch (p.work_ctr != nullptr, round 3): the
+	// grid is what is resident at once and every workgroup PULLS items -- from the counter of its own XCD
+	// first (item ids = XCD mod 8, as the hardware deals plain blocks: the row chunks {x, x + 8, ..} of a
+	// query tile stay on one L2), from the other XCDs' counters when its own is exhausted.  Workgroups of
+	// equal work finish 2-4 % apart by XCD (DVFS), so the dealt launch ended on its slowest XCD.
+	const uint32_t n_items = p.work_ctr ? p.n_items : gridDim.x;
+	auto item_body = [&](uint32_t bid) __attribute__((always_inline)) {
+	uint32_t qtile = bid % p.n_qtiles;
+	uint32_t chunk = bid / p.n_qtiles;
 	if (p.xcd_map) {
-		const uint32_t j = blockIdx.x >> 3;
+		const uint32_t j = bid >> 3;
 		qtile = j % p.n_qtiles;
-		chunk = (blockIdx.x & 7) + 8 * (j / p.n_qtiles);
+		chunk = (bid & 7) + 8 * (j / p.n_qtiles);
 	}
 	const uint32_t wg_q0 = qtile * WGQ;
 	const uint32_t q0 = wg_q0 + wave * 64;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	}
 	if (t1 > p.n_tiles_sel)
 		t1 = p.n_tiles_sel;
-	uint32_t* const my_log_cnt = p.log_cnt + (size_t)blockIdx.x * WAVES + wave;
+	uint32_t* const my_log_cnt = p.log_cnt + (size_t)bid * WAVES + wave;
 	if (t0 >= t1) {
 		if (SAMPLE) {  // (the host plans no empty chunk; if one appears its class maxima are "no row")
 			for (uint32_t i = lane; i < 64 * 32; i += 64)
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	// query's counter cost a round trip to L2 per flush and 98 MB of write traffic per launch).
 	uint32_t wfill = 0;   // wave-uniform: entries in the LDS queue
 	uint32_t glog_n = 0;  // wave-uniform: entries in this wave's global log
-	uint4* const my_log = p.log + ((size_t)blockIdx.x * WAVES + wave) * p.log_cap;
+	uint4* const my_log = p.log + ((size_t)bid * WAVES + wave) * p.log_cap;
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		for (uint32_t base = 0; base < n * 16; base += 64) {
@@ -474,8 +482,8 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (p.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {
-		unsigned long long* c = p.clk + (blockIdx.x == 0 ? 0 : 8);  // (first and last workgroup of the grid)
+	if (p.clk && (bid == 0 || bid == n_items - 1) && tid == 0) {
+		unsigned long long* c = p.clk + (bid == 0 ? 0 : 8);  // (first and last workgroup of the grid)
 		c[0] = clock64() - clk0;
 		c[1] = wall_clock64() - wall0;
 		for (int i = 0; i < 4; ++i)
@@ -483,15 +491,56 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		c[6] = t1 - t0;
 		c[7] = wall0;
 	}
-	if (p.clk && tid == 0 && blockIdx.x < 65536) {  // (debug 16: every workgroup's start / end on the 100 MHz clock, and its CU;
+	if (p.clk && tid == 0 && bid < 65536) {  // (debug 16: every workgroup's start / end on the 100 MHz clock, and its CU;
 	                                                 // the host's buffer holds 65 536 records)
-		p.clk[18 + 3 * (size_t)blockIdx.x] = wall0;
-		p.clk[19 + 3 * (size_t)blockIdx.x] = wall_clock64();
+		p.clk[18 + 3 * (size_t)bid] = wall0;
+		p.clk[19 + 3 * (size_t)bid] = wall_clock64();
 		uint32_t hwid;
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
 		uint32_t xcc;
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-		p.clk[20 + 3 * (size_t)blockIdx.x] = ((unsigned long long)xcc << 32) | hwid;
+		p.clk[20 + 3 * (size_t)bid] = ((unsigned long long)xcc << 32) | hwid;
+	}
+	};
+	// (ONE inlined copy of the item's code per instance: the sampled pass and d = 64 -- three workgroups per
+	// CU on 168 registers, none to spare for the loop's state -- are always launched plainly)
+	if constexpr (SAMPLE || D != 128) {
+		item_body(blockIdx.x);
+	} else {
+		const bool persist = p.work_ctr != nullptr;
+		uint32_t* const pick_slot = reinterpret_cast<uint32_t*>(smem + gemm_f16x_lds_bytes<D>() - 16);  // (behind `fills`)
+		uint32_t xcc = 0, live = 0xFFu;  // tid 0: queues that may still hold items
+		if (persist && tid == 0) {
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			xcc &= 7u;
+		}
+		for (bool first = true;; first = false) {
+			uint32_t item = blockIdx.x;
+			if (persist) {
+				if (tid == 0) {
+					uint32_t got = 0xFFFFFFFFu;
+					for (uint32_t r = 0; r < 8 && got == 0xFFFFFFFFu; ++r) {
+						const uint32_t y = (xcc + r) & 7u;
+						if (!(live & (1u << y)))
+							continue;
+						const uint32_t id = 8u * atomicAdd(p.work_ctr + 16 * y, 1u) + y;
+						if (id < n_items)
+							got = id;
+						else
+							live &= ~(1u << y);
+					}
+					*pick_slot = got;
+				}
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+				item = *pick_slot;
+				asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (read before tid 0 picks again)
+				if (item == 0xFFFFFFFFu)
+					break;
+			} else if (!first) {
+				break;
+			}
+			item_body(item);
+		}
 	}
 }
 
