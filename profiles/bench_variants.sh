@@ -5,10 +5,10 @@ import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
 print(' '.join(sys.argv[1:]), '| QPS', j['value'], 'ms/step', j['ms_per_step'], 'scan_ms', r['kernel_ms'], r['kernel'], 'frac', r['frac'], 'cands', r['candidates_per_query'])" "$@"; }
 if [ $# -gt 0 ]; then run "$@"; exit 0; fi
-# round 2: the 16x16x32 form of the fp16 scan (default at d = 128) next to round 1's kernel
+# round 3: persistent launch of the d = 128 scan (resident workgroups pull items) next to the plain launch
 for args in "" "--clustered 1000" "--k 100 --rows 1250000" "--metric ip" "--queries 1000" "--queries 256" "--sift-like"; do
   run --steps 10 $args
-  EXPANN_F16X=0 run --steps 10 $args | sed 's/^/   round-1 kernel: /'
+  EXPANN_PERSIST=0 run --steps 10 $args | sed 's/^/   plain launch: /'
 done
 run --n 1250000 --k 100 --steps 5
 run --n 10000000 --k 100 --steps 3
