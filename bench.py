@@ -365,8 +365,11 @@ def main():
         fail(f"WORLD_SIZE={world} but --gpus {G}: launch `python -m torch.distributed.run --nproc-per-node {G} "
              f"bench.py --gpus {G}` or plain `python bench.py --gpus {G}`")
     inproc = world == 1 and G > 1
-    from expann_amd import _lib
-    n_dev = _lib.load().expann_device_count()
+    # (torch BEFORE the library: the library then binds to the HIP and RCCL copies torch bundles -- one runtime,
+    # one RCCL in the process -- expann_amd/_lib.py; counting devices does not initialise the GPU)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process RCCL on this driver: dmabuf IPC only
+    import torch
+    n_dev = torch.cuda.device_count()
     need = G if inproc else (local_rank + 1 if world > 1 else 1)
     if n_dev < 1:
         fail(f"no HIP device visible; --gpus {G} needs {G} (libexpann_hip has no CPU fallback)")
@@ -374,7 +377,6 @@ def main():
         fail(f"--gpus {G} but only {n_dev} HIP device(s) visible"
              + ("" if inproc else f" (this is local rank {local_rank})")
              + "; set EXPANN_BENCH_REHEARSAL=1 to let the shards share devices (a rehearsal, not a measurement)")
-    import torch
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
