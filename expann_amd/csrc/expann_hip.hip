@@ -425,12 +425,12 @@ struct GemmF16Variant {
 // 6.83 M QPS at 1 M rows -- two k-steps per column leave too little MFMA per step; hence three here too)
 // d = 256 / 512: the 8-waves-per-tile geometry on 16x16x32 (scan_gemm_f16y.hpp), hits appended directly
 #define F16Y_V(D)                                                                                  \
-	{D, scan_gemm_f16y_kernel<D>, scan_gemm_f16_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
+	{D, scan_gemm_f16y_kernel<D, false>, scan_gemm_f16y_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
 	 "scan_gemm_f16y<" #D ", false>", kF16TB, F16Geom<D>::WGQ, F16Geom<D>::THREADS, F16Geom<D>::WG_PER_CU, \
 	 gemm_f16_lds_bytes<D>(), 0}
 // 512 < d <= 960: the k-split geometry on 16x16x32 (scan_gemm_f16kx.hpp)
 #define F16KX_V(D)                                                                                 \
-	{D, scan_gemm_f16kx_kernel<D>, scan_gemm_f16k_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
+	{D, scan_gemm_f16kx_kernel<D, false>, scan_gemm_f16kx_kernel<D, true>, sqnorm_kernel<D>, f16_query_prep_kernel<D>, \
 	 "scan_gemm_f16kx<" #D ", false>", F16kGeom<D>::TB, F16kGeom<D>::WGQ, F16kGeom<D>::THREADS, 1,     \
 	 F16kGeom<D>::LDS_BYTES, 0}
 const GemmF16Variant kGemmF16X[] = {F16X_V(64), F16X_V(128), F16Y_V(256), F16Y_V(512), F16KX_V(768), F16KX_V(832), F16KX_V(960)};
@@ -438,7 +438,7 @@ const GemmF16Variant kGemmF16X[] = {F16X_V(64), F16X_V(128), F16Y_V(256), F16Y_V
 #undef F16Y_V
 #undef F16X_V
 // the same with the run-time ablation switches compiled in ("debug" option != 0)
-const GemmF16Variant kGemmF16XDbg[] = {{128, scan_gemm_f16x_kernel<128, false, 1>, scan_gemm_f16_kernel<128, true>,
+const GemmF16Variant kGemmF16XDbg[] = {{128, scan_gemm_f16x_kernel<128, false, 1>, scan_gemm_f16x_kernel<128, true>,
                                         sqnorm_kernel<128>, f16_query_prep_kernel<128>, "scan_gemm_f16x<128, false>",
                                         kF16TB, kF16TQ, kF16Threads, 2, gemm_f16_lds_bytes<128>(), 1}};
 inline bool f16_choice(long opt) { return opt == 0 || opt == 4 || opt == 6; }

@@ -1,6 +1,7 @@
 // scan_gemm_f16.hpp -- the GEMM-form fp32 L2 candidate filter with ONE fp16 product per element
-// on the matrix cores (v_mfma_f32_32x32x16_f16): a third of the MFMA work of the bf16x3 form
-// (scan_gemm_bf16.hpp) and half its tile bytes.
+// on the matrix cores: a third of the MFMA work of the bf16x3 form (scan_gemm_bf16.hpp) and half its
+// tile bytes.  This header holds the analysis and everything the fp16 kernels share; the kernels
+// themselves are scan_gemm_f16x.hpp / f16y / f16kx (v_mfma_f32_16x16x32_f16).
 //
 // Every value is scaled by a per-index power of two s (so that max|x|*s <= 2^15) and rounded
 // once to fp16:  |x*s - fp16(x*s)| <= 2^-11 |x*s| + 2^-25  (normal + subnormal range).  Hence
@@ -350,214 +351,11 @@ static_assert(gemm_f16_lds_bytes<64>() * 3 <= 160 * 1024 &&
                   gemm_f16_lds_bytes<256>() <= 160 * 1024 && gemm_f16_lds_bytes<512>() <= 160 * 1024,
               "LDS budget per CU");
 
-template <int D, bool SAMPLE>
-__global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16_kernel(GemmF16Params p) {
-	static_assert(SAMPLE, "round 3: the 32 x 32 x 16 stream serves the sampled pass only (d = 256 / 512); the full scans are scan_gemm_f16x / f16y");
-	static_assert(D == 64 || D == 128 || D == 256 || D == 512, "built for d = 64, 128, 256, 512");
-	using G = F16Geom<D>;
-	constexpr int THREADS = G::THREADS, WAVES = G::WAVES, TQW = G::TQW, WGQ = G::WGQ;
-	constexpr bool NATURAL = G::NATURAL;
-	constexpr int ROWB = D * 2;      // bytes per fp16 row
-	constexpr int CH = ROWB / 16;    // 16-byte chunks per row
-	constexpr int KS = D / 16;       // MFMA k-steps; lane half h of k-step s: chunk h*KS + s, or 2s + h
-	constexpr int TILE_BYTES = kF16TB * ROWB;
-	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;  // rows per 256-byte LDS bank row
-	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
-	constexpr int NBUF = G::NBUF, PF = NBUF - 1;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-	const int tid = threadIdx.x;
-	const int lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int h = lane >> 5, r31 = lane & 31;
-	uint32_t qtile = blockIdx.x % p.n_qtiles;
-	uint32_t chunk = blockIdx.x / p.n_qtiles;
-	if (p.xcd_map) {
-		const uint32_t j = blockIdx.x >> 3;
-		qtile = j % p.n_qtiles;
-		chunk = (blockIdx.x & 7) + 8 * (j / p.n_qtiles);
-	}
-	const uint32_t wg_q0 = qtile * WGQ;
-	const uint32_t q0 = wg_q0 + wave * 32 * TQW;  // this wave's queries
-
-	const uint32_t t0 = chunk * p.tiles_per_block;
-	uint32_t t1 = t0 + p.tiles_per_block;
-	if (t1 > p.n_tiles_sel)
-		t1 = p.n_tiles_sel;
-	if (t0 >= t1)
-		return;  // (whole workgroup)
-	const unsigned long long clk0 = p.clk ? clock64() : 0, wall0 = p.clk ? wall_clock64() : 0;
-
-	// LDS map
-	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
-	f16x8 a[TQW][KS];
-#pragma unroll
-	for (int tq = 0; tq < TQW; ++tq) {
-		uint32_t qi = q0 + tq * 32 + r31;
-		if (qi >= p.m)
-			qi = p.m - 1;
-		const f16x8* src = reinterpret_cast<const f16x8*>((const unsigned char*)p.queries_f16 +
-		                                                  (size_t)qi * ROWB);
-#pragma unroll
-		for (int s = 0; s < KS; ++s)
-			a[tq][s] = src[NATURAL ? 2 * s + h : h * KS + s];
-	}
-	// the accumulators start at zero; th holds the running class maxima of g
-	f32x16 th[TQW];
-#pragma unroll
-	for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-		for (int reg = 0; reg < 16; ++reg)
-			th[tq][reg] = -__builtin_inff();
-	// the query fragments and thresholds are in registers before the first stage load is issued:
-	// a later wait for them would be a vmcnt(0) inside the loop and drain the prefetch queue
-#pragma unroll
-	for (int tq = 0; tq < TQW; ++tq) {
-#pragma unroll
-		for (int s = 0; s < KS; ++s)
-			asm volatile("" : "+v"(a[tq][s]));
-		asm volatile("" : "+v"(th[tq]));
-	}
-	// per-lane LDS offset of k-step s (row r31 of the first column tile); the second column tile
-	// is 32 rows further, where the swizzle term is the same
-	static_assert((32 / RPB) % (SWM + 1) == 0, "swizzle must repeat every 32 rows");
-	// natural order: chunk 2s + h = 16 (s >> 3) + (2 (s & 7) + h); the XOR with the row's swizzle
-	// (< 16) only touches the low part, so 8 registers + immediates address every k-step
-	constexpr int NA = NATURAL ? 8 : KS;
-	uint32_t aoff[NA];
-#pragma unroll
-	for (int j = 0; j < NA; ++j)
-		aoff[j] = r31 * ROWB + (((NATURAL ? 2 * j + h : h * KS + j) ^ ((r31 / RPB) & SWM)) * 16);
-
-	auto tile_row0 = [&](uint32_t t) -> uint32_t {
-		return ((t / p.tile_run) * (p.tile_stride * p.tile_run) + (t % p.tile_run)) * kF16TB;
-	};
-
-	// Staging: every wave issues N_STAGE + 1 LDS-DMA loads per tile (its share of the tile, and
-	// the bn' of the 64 rows into a slot of its own), every step, with no branches -- the last
-	// steps re-stage the final tile into a free buffer -- so the stage loads sit in the same
-	// basic block as the MFMAs and the vmcnt arithmetic is a constant.
-	// piece i of a thread is slot S = i*THREADS + tid of the tile (16 bytes each, LDS order =
-	// row-major physical chunks); its source is the logical chunk pc ^ swizzle(row)
-	constexpr int N_STAGE = kF16TB * CH / THREADS;
-	static_assert(kF16TB * CH % THREADS == 0, "whole staging rounds");
-	constexpr int LOADS = N_STAGE + 1;
-	uint32_t soff[N_STAGE];
-#pragma unroll
-	for (int i = 0; i < N_STAGE; ++i) {
-		const uint32_t S = i * THREADS + tid;
-		const uint32_t r = S / CH, pc = S % CH;
-		soff[i] = r * ROWB + ((pc ^ ((r / RPB) & SWM)) * 16);
-	}
-	// piece i of a tile's stage: i < N_STAGE the wave's i-th 1 KiB of the tile, i == N_STAGE the bn'
-	auto stage_piece = [&](const unsigned char* tb, uint32_t row0, int buf, int i) {
-		if (i < N_STAGE) {
-			unsigned char* dst0 = smem + buf * TILE_BYTES + wave * 64 * 16;
-			__builtin_amdgcn_global_load_lds(
-			    (const __attribute__((address_space(1))) void*)(tb + soff[i < N_STAGE ? i : 0]),
-			    (__attribute__((address_space(3))) void*)(dst0 + i * THREADS * 16), 16, 0, 0);
-		} else {
-			__builtin_amdgcn_global_load_lds(
-			    (const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
-			    (__attribute__((address_space(3))) void*)(bn_slots + (buf * WAVES + wave) * 256), 4, 0, 0);
-		}
-	};
-	auto stage_src = [&](uint32_t t, uint32_t& row0) -> const unsigned char* {
-		if (t > t1 - 1)
-			t = t1 - 1;
-		row0 = tile_row0(t);
-		return (const unsigned char*)p.base_f16 + (size_t)row0 * ROWB;
-	};
-	auto stage = [&](uint32_t t, int buf) {
-		uint32_t row0;
-		const unsigned char* tb = stage_src(t, row0);
-#pragma unroll
-		for (int i = 0; i < LOADS; ++i)
-			stage_piece(tb, row0, buf, i);
-	};
-	auto read_bn = [&](float (&bnv)[2], int buf) {
-		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * WAVES + wave) * 256);
-		bnv[0] = slot[r31];
-		bnv[1] = slot[32 + r31];
-	};
-
-#pragma unroll
-	for (int i = 0; i < PF; ++i)
-		stage(t0 + i, i);
-	wait_vm_then_barrier<(PF - 1) * LOADS>();  // tile t0 landed
-
-	f32x16 acc[TQW][2];
-	f32x16 zero16;
-#pragma unroll
-	for (int e = 0; e < 16; ++e)
-		zero16[e] = 0.0f;
-	float bnv[2];
-	int buf = 0, pbuf = PF;  // pbuf: buffer that tile t+PF goes to (= the one tile t-1 used)
-	for (uint32_t t = t0; t < t1; ++t) {
-		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
-		auto frag = [&](int tc, int s) -> f16x8 {
-			const uint32_t o = NATURAL ? aoff[s & 7] + (s >> 3) * 256 : aoff[NATURAL ? 0 : s];
-			return *reinterpret_cast<const f16x8*>(smem + (boff + o) + tc * 32 * ROWB);
-		};
-		// Order pinned by scheduling barriers: the fragments of k-step s+2 are requested before
-		// the MFMAs of k-step s issue, and the stage loads of tile t+PF go out one per k-step,
-		// in the shadow of the MFMAs (an LDS-DMA issue costs 60-180 cycles of the wave's time).
-		uint32_t srow0;
-		const unsigned char* stb = stage_src(t + PF, srow0);
-		static_assert(LOADS <= KS, "one stage piece per k-step");
-		constexpr int FD = D >= 512 ? 1 : 2;  // k-steps of fragment read-ahead (d = 512: registers)
-		f16x8 fb[KS][2];
-#pragma unroll
-		for (int s = 0; s < FD; ++s) {
-			fb[s][0] = frag(0, s);
-			fb[s][1] = frag(1, s);
-		}
-		read_bn(bnv, buf);
-		__builtin_amdgcn_s_setprio(1);
-		__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-		for (int s = 0; s < KS; ++s) {
-			if (s + FD < KS) {  // FD k-steps ahead: a wait for k-step s+1 never meets a fresh request
-				fb[s + FD][0] = frag(0, s + FD);
-				fb[s + FD][1] = frag(1, s + FD);
-			}
-#pragma unroll
-			for (int tq = 0; tq < TQW; ++tq) {
-				acc[tq][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][0], s == 0 ? zero16 : acc[tq][0], 0, 0, 0);
-				acc[tq][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tq][s], fb[s][1], s == 0 ? zero16 : acc[tq][1], 0, 0, 0);
-			}
-			if (s < LOADS)
-				stage_piece(stb, srow0, pbuf, s);
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		__builtin_amdgcn_s_setprio(0);
-		// running maxima of g per (query register, row class = lane); a NaN bn' (padding row)
-		// never wins a max
-#pragma unroll
-		for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-			for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-				for (int reg = 0; reg < 16; ++reg)
-					th[tq][reg] = __builtin_fmaxf(th[tq][reg], acc[tq][tc][reg] - bnv[tc]);
-		wait_vm_then_barrier<(PF - 1) * LOADS>();
-		pbuf = buf;
-		buf = buf + 1 == NBUF ? 0 : buf + 1;
-	}
-#pragma unroll
-	for (int tq = 0; tq < TQW; ++tq)
-#pragma unroll
-		for (int reg = 0; reg < 16; ++reg) {
-			const uint32_t qi = q0 + tq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			if (qi < p.m)
-				p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + r31] = th[tq][reg];
-		}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tiles: LDS must outlive them
-	if (p.clk && blockIdx.x == 0 && tid == 0) {
-		p.clk[0] = clock64() - clk0;
-		p.clk[1] = wall_clock64() - wall0;
-	}
-}
+// (Rounds 1-2 ran this filter -- full scan and sampled pass -- on v_mfma_f32_32x32x16_f16 in a kernel of this
+// file, scan_gemm_f16_kernel<D, SAMPLE>; since round 3 every fp16 stream is one of the 16 x 16 x 32 kernels
+// scan_gemm_f16x (d = 64 / 128), f16y (256 / 512), f16kx (768 - 960), each with a SAMPLE instance.  What stays
+// here is what they share: parameters, geometry and LDS budget, the index / query conversions, the hit logs'
+// gather, the thresholds from the sampled pass.)
 
 // tau[q] = an upper bound of the k-th smallest reference-order score over the sampled rows, from
 // the n_vals class maxima of g written by the SAMPLE pass.  The SAMPLE pass subtracts the UPPER

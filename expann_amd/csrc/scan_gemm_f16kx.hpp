@@ -13,7 +13,10 @@
 
 namespace expann {
 
-template <int D>
+// SAMPLE (round 3): the sampled pass on the same stream -- the first-half wave's accumulators start at -bn'
+// (the row term as the MFMA's C operand), after the exchange it keeps the running maximum of g per (query
+// register, row class = 16 column + lane & 15); as scan_gemm_f16x_kernel<D, true>.
+template <int D, bool SAMPLE = false>
 __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p) {
 	static_assert(D == 768 || D == 832 || D == 960, "built for d = 768, 832, 960");
 	using G = F16kGeom<D>;
@@ -82,10 +85,16 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
-			th[tq][r] = kh == 0 ? (qi < p.m ? p.theta[qi] : -__builtin_inff()) : 0.0f;
+			th[tq][r] = kh == 0 ? ((qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff()) : 0.0f;
 		}
-	if (tid < WGQ)
+	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
+	f32x4 smax[2][2];  // SAMPLE: running class maxima [column][query tile]
+#pragma unroll
+	for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+			smax[tc][tq] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 	if (tid < 8)
 		fills[tid] = 0;
 #pragma unroll
@@ -242,6 +251,12 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p
 		// the bn' of this tile: its slot is re-staged during the NEXT step, so it is read now
 		const float* bslot = reinterpret_cast<const float*>(bn_slots + buf * 256);
 		const float bnv[2] = {bslot[l15], bslot[16 + l15]};
+		f32x4 c0[2];  // SAMPLE: the first-half wave starts at -bn' of its lane's rows, the second at zero
+#pragma unroll
+		for (int tc = 0; tc < 2; ++tc) {
+			const float v = kh == 0 ? -bnv[tc] : 0.0f;
+			c0[tc] = f32x4{v, v, v, v};
+		}
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -254,7 +269,8 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p
 			for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
 				for (int tc = 0; tc < 2; ++tc)
-					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], fb[s][tc], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], fb[s][tc],
+					                                                     s == 0 ? (SAMPLE ? c0[tc] : th[tq]) : acc[tq][tc], 0, 0, 0);
 			{
 				if (2 * s < LOADS)
 					stage_piece(stb, srow0, buf ^ 1, 2 * s);
@@ -296,7 +312,15 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p
 				acc[j >> 1][j & 1][2] += v.z;
 				acc[j >> 1][j & 1][3] += v.w;
 			}
-			{
+			if constexpr (SAMPLE) {
+#pragma unroll
+				for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+					for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+						for (int r = 0; r < 4; ++r)
+							smax[tc][tq][r] = __builtin_fmaxf(smax[tc][tq][r], acc[tq][tc][r]);
+			} else {
 				// queue fills posted at the previous step are visible after this step's barrier: if a
 				// queue of the workgroup is half full, every wave empties its own now
 				if (since_look == kF16FlushEvery) {
@@ -315,8 +339,22 @@ __global__ __launch_bounds__(512, 2) void scan_gemm_f16kx_kernel(GemmF16Params p
 		buf ^= 1;
 		par ^= 1;
 	}
-	if (!kh)
-		flush_own();
+	if (!kh) {
+		if constexpr (SAMPLE) {
+#pragma unroll
+			for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+				for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
+						if (qi < p.m)
+							p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + tc * 16 + l15] = smax[tc][tq][r];
+					}
+		} else {
+			flush_own();
+		}
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tile: LDS must outlive it
 }
 

@@ -6,14 +6,16 @@
 // accumulators of one 16-row column -- 2 query tiles x 4 registers -- share ONE row term bn': one max
 // tree + compare per column.  A = queries: lane l holds query l & 15 of tile tq, 16-byte chunk 4 s +
 // (l >> 4) of its row; B = base rows from LDS: row l & 15 of column tc, same chunk; C: lane l,
-// register r = query 4 (l >> 4) + r of tile tq against row l & 15 of column tc.  The sampled pass
-// keeps scan_gemm_f16_kernel<D, true>.
+// register r = query 4 (l >> 4) + r of tile tq against row l & 15 of column tc.
+// SAMPLE (round 3): the sampled pass on the same stream, as scan_gemm_f16x_kernel<D, true> -- the row term
+// enters as the MFMA's C operand (the accumulators start at -bn'), the epilogue is the running maximum of
+// g per (query register, row class = 16 (column & 1) + lane & 15), two columns of equal parity per v_max3.
 #pragma once
 #include "scan_gemm_f16x.hpp"
 
 namespace expann {
 
-template <int D>
+template <int D, bool SAMPLE = false>
 __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(GemmF16Params p) {
 	static_assert(D == 256 || D == 512, "the 8-waves-per-tile geometry of scan_gemm_f16.hpp");
 	using G = F16Geom<D>;
@@ -78,10 +80,16 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
-			th[tq][r] = qi < p.m ? p.theta[qi] : -__builtin_inff();
+			th[tq][r] = (qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff();
 		}
-	if (tid < WGQ)
+	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
+	f32x4 smax[2][2];  // SAMPLE: running class maxima [column parity][query tile]
+#pragma unroll
+	for (int par = 0; par < 2; ++par)
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+			smax[par][tq] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
 	for (int tq = 0; tq < 2; ++tq) {
 #pragma unroll
@@ -216,6 +224,10 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			bv[tc] = slot[tc * 16 + l15];
+		f32x4 c0[4];  // SAMPLE: -bn' of this lane's row in every column
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc)
+			c0[tc] = f32x4{-bv[tc], -bv[tc], -bv[tc], -bv[tc]};
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -229,7 +241,8 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 			for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
 				for (int tc = 0; tc < 4; ++tc)
-					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], fb[s][tc], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], fb[s][tc],
+					                                                     s == 0 ? (SAMPLE ? c0[tc] : th[tq]) : acc[tq][tc], 0, 0, 0);
 			constexpr int PER = (LOADS + KS - 1) / KS;
 #pragma unroll
 			for (int j = 0; j < PER; ++j)
@@ -238,38 +251,62 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		__builtin_amdgcn_s_setprio(0);
-		// one max tree + compare per 16-row column, one wave-uniform test per step
-		float gmax[4];
+		if constexpr (SAMPLE) {
 #pragma unroll
-		for (int tc = 0; tc < 4; ++tc)
-			gmax[tc] = __builtin_fmaxf(max3f(acc[0][tc][0], acc[0][tc][1], acc[0][tc][2]),
-			                           max3f(acc[0][tc][3], acc[1][tc][0], max3f(acc[1][tc][1], acc[1][tc][2], acc[1][tc][3])));
-		const bool h0 = gmax[0] >= bv[0], h1 = gmax[1] >= bv[1], h2 = gmax[2] >= bv[2], h3 = gmax[3] >= bv[3];
-		if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {
-			const uint32_t row0 = tile_row0(t);
-			const unsigned long long k0 = __builtin_amdgcn_ballot_w64(h0), k1 = __builtin_amdgcn_ballot_w64(h1),
-			                         k2 = __builtin_amdgcn_ballot_w64(h2), k3 = __builtin_amdgcn_ballot_w64(h3);
-			if (k0) push_hits(acc, 0, k0, h0, bv[0], row0);
-			if (k1) push_hits(acc, 1, k1, h1, bv[1], row0);
-			if (k2) push_hits(acc, 2, k2, h2, bv[2], row0);
-			if (k3) push_hits(acc, 3, k3, h3, bv[3], row0);
-		}
-		if (wfill >= (uint32_t)QCAP * 3 / 4)
-			flush_own();
-		const bool look = ++since_look == kF16FlushEvery;
-		if (look && lane == 0)
-			fills[wave] = wfill;
-		wait_vm_then_barrier<(PF - 1) * LOADS>();
-		if (look) {
-			since_look = 0;
-			const uint32_t f = fills[lane & (WAVES - 1)];
-			if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
+			for (int par = 0; par < 2; ++par)
+#pragma unroll
+				for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						smax[par][tq][r] = max3f(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
+		} else {
+			// one max tree + compare per 16-row column, one wave-uniform test per step
+			float gmax[4];
+	#pragma unroll
+			for (int tc = 0; tc < 4; ++tc)
+				gmax[tc] = __builtin_fmaxf(max3f(acc[0][tc][0], acc[0][tc][1], acc[0][tc][2]),
+				                           max3f(acc[0][tc][3], acc[1][tc][0], max3f(acc[1][tc][1], acc[1][tc][2], acc[1][tc][3])));
+			const bool h0 = gmax[0] >= bv[0], h1 = gmax[1] >= bv[1], h2 = gmax[2] >= bv[2], h3 = gmax[3] >= bv[3];
+			if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {
+				const uint32_t row0 = tile_row0(t);
+				const unsigned long long k0 = __builtin_amdgcn_ballot_w64(h0), k1 = __builtin_amdgcn_ballot_w64(h1),
+				                         k2 = __builtin_amdgcn_ballot_w64(h2), k3 = __builtin_amdgcn_ballot_w64(h3);
+				if (k0) push_hits(acc, 0, k0, h0, bv[0], row0);
+				if (k1) push_hits(acc, 1, k1, h1, bv[1], row0);
+				if (k2) push_hits(acc, 2, k2, h2, bv[2], row0);
+				if (k3) push_hits(acc, 3, k3, h3, bv[3], row0);
+			}
+			if (wfill >= (uint32_t)QCAP * 3 / 4)
 				flush_own();
+			const bool look = ++since_look == kF16FlushEvery;
+			if (look && lane == 0)
+				fills[wave] = wfill;
+			wait_vm_then_barrier<(PF - 1) * LOADS>();
+			if (look) {
+				since_look = 0;
+				const uint32_t f = fills[lane & (WAVES - 1)];
+				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
+					flush_own();
+			}
 		}
 		pbuf = buf;
 		buf = buf + 1 == NBUF ? 0 : buf + 1;
 	}
-	flush_own();
+	if constexpr (SAMPLE) {
+#pragma unroll
+		for (int par = 0; par < 2; ++par)
+#pragma unroll
+			for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
+					if (qi < p.m)
+						p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + par * 16 + l15] = smax[par][tq][r];
+				}
+	} else {
+		flush_own();
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
