@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexpann_hip.so")
+LIB_PATH = os.environ.get("EXPANN_LIB") or os.path.join(_HERE, "libexpann_hip.so")  # (EXPANN_LIB: A/B runs of two builds)
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_BUILT, ERR_UNSUPPORTED, ERR_OVERFLOW = 1, 2, 3, 4, 5, 6

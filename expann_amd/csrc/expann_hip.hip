@@ -106,6 +106,8 @@ struct expann_index {
 	size_t log_bytes = 0, log_cnt_n = 0;
 	struct {                         // scatter_log_kernel of the scan just launched (run after its timing event)
 		uint32_t n_logs = 0, log_cap = 0, cap = 0, n_chunks = 0, n_qtiles = 0, xcd_map = 0, m = 0;
+		const float* theta = nullptr;  // fp16 logs: entries hold bn' - acc, the gather adds theta' and scales (GatherLogParams)
+		float key_mul = 0.0f;
 	} pending_scatter;
 	GrowPtr<float> d_sample;         // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
 	GrowPtr<void> d_q_split;         // [m][2][dim] bf16 (or [m][dim] fp16)
@@ -680,6 +682,8 @@ int ensure_hit_logs(expann_index* h, uint32_t grid, int waves, size_t m, uint32_
 	h->pending_scatter.n_qtiles = n_qtiles;
 	h->pending_scatter.xcd_map = xcd_map;
 	h->pending_scatter.m = (uint32_t)m;
+	h->pending_scatter.theta = nullptr;
+	h->pending_scatter.key_mul = 0.0f;
 	return EXPANN_OK;
 }
 
@@ -694,7 +698,7 @@ void launch_gather_logs(expann_index* h, hipStream_t st) {
 	const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
 	const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
 	GatherLogParams gp{h->d_log.as<const uint4>(), h->d_log_cnt.as<const uint32_t>(), ps.log_cap, ps.n_chunks,
-	                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap};
+	                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap, ps.theta, ps.key_mul};
 	hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
 }
 
@@ -1362,6 +1366,8 @@ int launch_scan_f16(expann_index* h, const GemmF16Variant* gvf, uint32_t rows_se
 			if (lrc != EXPANN_OK)
 				return lrc;
 			fp.lost = h->d_overflow;
+			h->pending_scatter.theta = fp.theta;
+			h->pending_scatter.key_mul = fp.two_inv_s2;
 		}
 		uint32_t launch_grid = grid;
 		const uint32_t resident = (uint32_t)gvf->wg_per_cu * (uint32_t)cus;

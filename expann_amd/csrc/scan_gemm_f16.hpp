@@ -221,7 +221,7 @@ struct GemmF16Params {
 	// the launch ends on the small ones and drains in a third of the time (pick_tail_chunks).
 	uint32_t n_big, tiles_small;
 	// scan_gemm_f16x_kernel only: every wave appends its hits to a log of its own in global memory --
-	// log[(4 blockIdx.x + wave) * log_cap + i] = {key, query}, plain stores in the wave's own order, no
+	// log[(4 blockIdx.x + wave) * log_cap + i] = {bn' - acc, row, query}, plain stores in the wave's own order, no
 	// atomic and no returned value to wait for inside the MFMA kernel -- and leaves the count in
 	// log_cnt; scatter_log_kernel then files the entries into the per-query lists (cand, cand_cnt).
 	// *lost is incremented by a wave whose log or LDS queue overflowed (the host repeats the search
@@ -250,6 +250,11 @@ struct GatherLogParams {
 	uint32_t* cand_cnt;
 	uint64_t* cand;
 	uint32_t cap;
+	// fp16 logs (scan_gemm_f16x.hpp): an entry is {bits of bn' - acc, row, query}; the key is made HERE,
+	// make_key((x + theta[query]) * key_mul, row) -- the arithmetic the scan's flush used to do behind a second
+	// LDS round trip.  nullptr (scan_gemm_i8w.hpp): entries hold the finished key in x, y.
+	const float* theta;
+	float key_mul;
 };
 __global__ __launch_bounds__(kBlock) void gather_logs_kernel(GatherLogParams p) {
 	__shared__ uint32_t cnt[64], base[64];
@@ -291,7 +296,9 @@ __global__ __launch_bounds__(kBlock) void gather_logs_kernel(GatherLogParams p) 
 			const uint32_t ql = (e.z - q0) & 63;
 			const uint32_t slot = base[ql] + atomicAdd(&cnt[ql], 1u);
 			if (slot < p.cap)
-				p.cand[(size_t)e.z * p.cap + slot] = ((uint64_t)e.y << 32) | e.x;
+				p.cand[(size_t)e.z * p.cap + slot] =
+				    p.theta ? make_key((__builtin_bit_cast(float, e.x) + p.theta[e.z]) * p.key_mul, e.y)
+				            : ((uint64_t)e.y << 32) | e.x;
 		}
 	}
 }

@@ -49,6 +49,10 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	constexpr int THREADS = kF16Threads, WAVES = kF16Waves, WGQ = kF16TQ, QCAP = f16x_qcap<D>();
 	constexpr int ROWB = D * 2, CH = ROWB / 16;
 	constexpr int KS = D / 32;  // MFMA k-steps of 32
+#ifndef EXPANN_F16X_SPLIT
+#define EXPANN_F16X_SPLIT 1
+#endif
+	constexpr int SPLIT = EXPANN_F16X_SPLIT;  // k-steps of a column issued before the next column's fragment reads
 	constexpr int TILE_BYTES = kF16TB * ROWB;
 	constexpr int RPB = (ROWB < 256) ? 256 / ROWB : 1;
 	constexpr int SWM = (CH < 16 ? CH : 16) - 1;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	};
 	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
 	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * WAVES * 256) + wave * QCAP;
-	float* const thq = reinterpret_cast<float*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
+	// (behind the queues: WGQ words that held theta' for the flush's keys until round 3 -- the map is shared with f16y)
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes) + WGQ;
 
 	f16x8 a[4][KS];
 #pragma unroll
@@ -137,8 +141,6 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
 			th[tq][r] = (qi < p.m && !SAMPLE) ? p.theta[qi] : -__builtin_inff();
 		}
-	if (!SAMPLE && tid < WGQ)
-		thq[tid] = wg_q0 + tid < p.m ? p.theta[wg_q0 + tid] : -__builtin_inff();
 #pragma unroll
 	for (int tq = 0; tq < 4; ++tq) {
 #pragma unroll
@@ -203,23 +205,35 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	uint4* const my_log = p.log + ((size_t)bid * WAVES + wave) * p.log_cap;
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		for (uint32_t base = 0; base < n * 16; base += 64) {
-			const uint32_t i = base + lane;
-			const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
-			const uint32_t v = i & 15;
-			const float c = e.acc[v], bn = e.bn;
-			const bool hit = i < n * 16 && c >= bn;
-			const uint32_t qi = e.qrow0 + 16 * (v >> 2) + (v & 3);
-			// approximate key of a hit: bn(1-eps) - abs|b| - 2 q16.b16/s^2 = ((bn' - acc) + theta') * 2/s^2
-			const uint64_t key = make_key(((bn - c) + thq[(qi - wg_q0) & (WGQ - 1)]) * p.two_inv_s2, e.row);
-			const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-			if (mask == 0 || (dbg & 64))
-				continue;
-			const uint32_t pos = glog_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-			                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-			if (hit && pos < p.log_cap)
-				my_log[pos] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), qi, 0u);
-			glog_n += (uint32_t)__builtin_popcountll(mask);
+		// 16 lanes per entry, TWO rounds of 4 entries in flight (their LDS reads share one wait); a log entry is
+		// {bn' - acc, row, query}: gather_logs_kernel adds theta' and makes the key (no second LDS round trip here)
+		for (uint32_t base = 0; base < n * 16; base += 128) {
+			bool hit[2];
+			float dv[2];
+			uint32_t row[2], qi[2];
+			unsigned long long mask[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				const uint32_t i = base + 64 * u + lane;
+				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
+				const uint32_t v = i & 15;
+				const float c = e.acc[v], bn = e.bn;
+				hit[u] = i < n * 16 && c >= bn;
+				qi[u] = e.qrow0 + 16 * (v >> 2) + (v & 3);
+				row[u] = e.row;
+				dv[u] = bn - c;
+			}
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				mask[u] = __builtin_amdgcn_ballot_w64(hit[u]);
+				if (mask[u] == 0 || (dbg & 64))
+					continue;
+				const uint32_t pos = glog_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32),
+				                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0u));
+				if (hit[u] && pos < p.log_cap)
+					my_log[pos] = make_uint4(__builtin_bit_cast(uint32_t, dv[u]), row[u], qi[u], 0u);
+				glog_n += (uint32_t)__builtin_popcountll(mask[u]);
+			}
 		}
 		wfill = 0;
 	};
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 			smax[par][tq] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 	stage(t0, 0);
 	stage(t0 + 1, 1);
-	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles t0, t0+1 landed, thq visible
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles t0, t0+1 landed, fills visible
 
 	f32x4 acc[4][4];
 	int buf = 0;
@@ -323,12 +337,16 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 			for (int r = 0; r < 4; ++r)
 				smax[par][tq][r] = max3f(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
 	};
-	auto mfma_col = [&](int tc, const f16x8 (&f)[KS]) {
+	// k-steps [s0, s1) of tile column tc.  A column is issued in two parts -- k-step 0, then the rest -- with
+	// the NEXT column's fragment reads between them: the compiler puts an lgkmcnt(0) in front of the first
+	// MFMA that follows LDS reads (it cannot see the waits of the barrier's inline asm), and with the reads
+	// in front of the column that wait exposed their whole round trip twice per step.
+	auto mfma_part = [&](int tc, const f16x8 (&f)[KS], int s0, int s1) {
 		if (SAMPLE) {
 			const float nb = -bnv[tc];
 			const f32x4 c0 = {nb, nb, nb, nb};
 #pragma unroll
-			for (int s = 0; s < KS; ++s)
+			for (int s = s0; s < s1; ++s)
 #pragma unroll
 				for (int tq = 0; tq < 4; ++tq)
 					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? c0 : acc[tq][tc], 0, 0, 0);
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		}
 		if (!PARTIAL) {
 #pragma unroll
-			for (int s = 0; s < KS; ++s)
+			for (int s = s0; s < s1; ++s)
 #pragma unroll
 				for (int tq = 0; tq < 4; ++tq)
 					acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
@@ -345,11 +363,12 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 #pragma unroll
 		for (int tq = 0; tq < 4; ++tq) {
 			if (tq >= n_tq) {
-				acc[tq][tc] = th[tq];
+				if (s0 == 0)
+					acc[tq][tc] = th[tq];
 				continue;
 			}
 #pragma unroll
-			for (int s = 0; s < KS; ++s)
+			for (int s = s0; s < s1; ++s)
 				acc[tq][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
 		}
 	};
@@ -364,6 +383,7 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 	for (int s = 0; s < KS; ++s)
 		fb[0][s] = frag(0, 0, s);
 	read_bn(bnv, 0);
+	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 	for (uint32_t t = t0; t < t1; ++t) {
 		const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;   // tile t+1
 		const int pbuf = buf == 0 ? NBUF - 1 : buf - 1;   // tile t-1 -> takes tile t+2
@@ -371,26 +391,40 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		float bnn[4];
 		__builtin_amdgcn_s_setprio(1);
 		// column 0 (its fragments came in during the previous step), column 1
+		mfma_part(0, fb[0], 0, SPLIT);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[1][s] = (dbg & 32) ? fb[0][0] : frag(buf, 1, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(0, fb[0]);
+		mfma_part(0, fb[0], SPLIT, KS);
+		__builtin_amdgcn_sched_barrier(0);
+		mfma_part(1, fb[1], 0, SPLIT);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[0][s] = (dbg & 32) ? fb[1][0] : frag(buf, 2, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(1, fb[1]);
-		if (!SAMPLE && !(dbg & 4))
+		mfma_part(1, fb[1], SPLIT, KS);
+		if (!SAMPLE && !(dbg & 4)) {
 			gmax[0] = col_max(0);
+			asm volatile("" : "+v"(gmax[0]));  // (computed HERE: between column 1's MFMAs, not sunk behind the barrier)
+		}
+		__builtin_amdgcn_sched_barrier(0);
 		__builtin_amdgcn_s_setprio(0);
 		stamp(0);
 		// ---- the step's barrier: tile t+1 landed, tile t-1 released ------------------------------
 		const bool look = !SAMPLE && ++since_look == kF16FlushEvery;
 		if (look && lane == 0)
 			fills[wave] = wfill;
-		if (!(dbg & 1))
-			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		if (!(dbg & 1)) {
+			// (builtins, not inline asm: the compiler's own wait insertion then knows that every LDS read issued
+			// so far has landed, and puts no lgkmcnt(0) behind the second half's first fragment reads)
+			asm volatile("" ::: "memory");
+			__builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+		}
 		stamp(1);
 		if (look) {
 			since_look = 0;
@@ -402,11 +436,13 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + 2, srow0);
 		__builtin_amdgcn_s_setprio(1);
+		mfma_part(2, fb[0], 0, SPLIT);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[1][s] = (dbg & 32) ? fb[0][0] : frag(buf, 3, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(2, fb[0]);
+		mfma_part(2, fb[0], SPLIT, KS);
 		if (!(dbg & 2)) {
 #pragma unroll
 			for (int i = 0; i < (LOADS + 1) / 2; ++i)
@@ -414,13 +450,16 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		}
 		if (!SAMPLE && !(dbg & 4))
 			gmax[1] = col_max(1);
+		__builtin_amdgcn_sched_barrier(0);
+		mfma_part(3, fb[1], 0, SPLIT);
+		__builtin_amdgcn_sched_barrier(0);
 		// column 0 of tile t+1 and its row terms (clamped past the end: the re-staged last tile)
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[0][s] = (dbg & 32) ? fb[1][0] : frag(nbuf, 0, s);
 		read_bn(bnn, nbuf);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(3, fb[1]);
+		mfma_part(3, fb[1], SPLIT, KS);
 		if (!(dbg & 2)) {
 #pragma unroll
 			for (int i = (LOADS + 1) / 2; i < LOADS; ++i)
@@ -451,6 +490,10 @@ __global__ __launch_bounds__(kF16Threads, f16x_wg_per_cu<D>()) void scan_gemm_f1
 		}
 		if (!SAMPLE && wfill >= (uint32_t)QCAP * 3 / 4)
 			flush_own();
+		// (tile t+1's first fragments and row terms were requested under column 3: they have landed; saying so
+		// here keeps the compiler from waiting for them -- and for whatever LDS read it has issued since -- in
+		// the middle of the next step's first column)
+		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			bnv[tc] = bnn[tc];
