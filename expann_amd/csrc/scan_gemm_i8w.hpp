@@ -250,9 +250,11 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 		m2 = max3i(m2, m3, m4);
 		return max(m0, m2);
 	};
-	auto mfma_col = [&](int tc, const i32x4 (&f)[KS]) {
+	// k-steps [s0, s1) of tile column tc; a column is issued as k-step 0, the NEXT column's fragment reads, the
+	// rest (scan_gemm_f16x.hpp: no lgkmcnt(0) in front of a column that exposes those reads' round trip)
+	auto mfma_part = [&](int tc, const i32x4 (&f)[KS], int s0, int s1) {
 #pragma unroll
-		for (int s = 0; s < KS; ++s)
+		for (int s = s0; s < s1; ++s)
 #pragma unroll
 			for (int tq = 0; tq < 4; ++tq)
 				acc[tq][tc] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
@@ -264,29 +266,40 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	for (int s = 0; s < KS; ++s)
 		fb[0][s] = frag_at(0, 0, s);
 	read_bp(bpv, 0);
+	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 	for (uint32_t t = t0; t < t1; ++t) {
 		const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;   // tile t+1
 		const int pbuf = buf == 0 ? NBUF - 1 : buf - 1;   // tile t-1 -> takes tile t+2
 		int gmax[4];
 		int bpn[4];
 		__builtin_amdgcn_s_setprio(1);
+		mfma_part(0, fb[0], 0, 1);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[1][s] = frag_at(buf, 1, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(0, fb[0]);
+		mfma_part(0, fb[0], 1, KS);
+		__builtin_amdgcn_sched_barrier(0);
+		mfma_part(1, fb[1], 0, 1);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[0][s] = frag_at(buf, 2, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(1, fb[1]);
+		mfma_part(1, fb[1], 1, KS);
 		gmax[0] = col_max(0);
+		asm volatile("" : "+v"(gmax[0]));  // (computed here, between column 1's MFMAs)
+		__builtin_amdgcn_sched_barrier(0);
 		__builtin_amdgcn_s_setprio(0);
 		// ---- the step's barrier: tile t+1 landed, tile t-1 released ------------------------------
 		const bool look = ++since_look == kF16FlushEvery;
 		if (look && lane == 0)
 			fills[wave] = wfill;
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as builtins: the compiler's wait insertion sees them
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
 		if (look) {
 			since_look = 0;
 			const uint32_t f = fills[lane & (WAVES - 1)];
@@ -297,21 +310,26 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + 2, srow0);
 		__builtin_amdgcn_s_setprio(1);
+		mfma_part(2, fb[0], 0, 1);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[1][s] = frag_at(buf, 3, s);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(2, fb[0]);
+		mfma_part(2, fb[0], 1, KS);
 #pragma unroll
 		for (int i = 0; i < (LOADS + 1) / 2; ++i)
 			stage_piece(stb, srow0, pbuf, i);
 		gmax[1] = col_max(1);
+		__builtin_amdgcn_sched_barrier(0);
+		mfma_part(3, fb[1], 0, 1);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int s = 0; s < KS; ++s)
 			fb[0][s] = frag_at(nbuf, 0, s);
 		read_bp(bpn, nbuf);
 		__builtin_amdgcn_sched_barrier(0);
-		mfma_col(3, fb[1]);
+		mfma_part(3, fb[1], 1, KS);
 #pragma unroll
 		for (int i = (LOADS + 1) / 2; i < LOADS; ++i)
 			stage_piece(stb, srow0, pbuf, i);
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 		}
 		if (wfill >= (uint32_t)QCAP * 3 / 4)
 			flush_own();
+		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): tile t+1's first fragments and row terms, requested under column 3
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			bpv[tc] = bpn[tc];
