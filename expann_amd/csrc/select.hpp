@@ -241,9 +241,14 @@ __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint
 	const uint32_t l = lane & 15, grp = lane >> 4;  // 16 lanes per candidate row
 	const float* q = p.rerank_queries + (size_t)qi * p.dim + l;
 	float cutoff = __builtin_inff();
-	if (p.prune_eps > 0.0f && c > p.k) {
+	// lists with FINAL scores (the 8-bit forms: no re-score) are cut at their k-th smallest score itself --
+	// what is left to rank is k keys + ties instead of the whole list (k = 100 on uint8 rows: 535 keys, each
+	// ranked against all of them, were 0.31 ms of a 2.4 ms step)
+	const bool final_scores = p.rerank_base == nullptr;
+	if ((p.prune_eps > 0.0f || final_scores) && c > p.k) {
 		float qn = 0.0f;
-		if (p.qnrm) {
+		if (final_scores) {
+		} else if (p.qnrm) {
 			qn = p.qnrm[qi];
 		} else {
 			for (uint32_t t = 0; t < p.dim / 16; ++t)
@@ -272,9 +277,13 @@ __device__ inline void select_wave_body(const SelectParams& p, uint32_t qi, uint
 			for (int j = 0; j < PER; ++j)
 				sc[j] = sc[j] == mn ? 0xFFFFFFFFu : sc[j];
 		}
-		const float bmax = p.bn_max[0];
-		cutoff = ordered_to_float(kth) + p.prune_eps * (qn + 1.5f * bmax) +
-		         p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
+		if (final_scores) {
+			cutoff = ordered_to_float(kth);
+		} else {
+			const float bmax = p.bn_max[0];
+			cutoff = ordered_to_float(kth) + p.prune_eps * (qn + 1.5f * bmax) +
+			         p.prune_abs * (__builtin_sqrtf(qn) + __builtin_sqrtf(bmax));
+		}
 	}
 	uint32_t n_s = 0;  // wave-uniform
 #pragma unroll
