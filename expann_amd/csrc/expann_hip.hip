@@ -108,6 +108,8 @@ struct expann_index {
 		uint32_t n_logs = 0, log_cap = 0, cap = 0, n_chunks = 0, n_qtiles = 0, xcd_map = 0, m = 0;
 		const float* theta = nullptr;  // fp16 logs: entries hold bn' - acc, the gather adds theta' and scales (GatherLogParams)
 		float key_mul = 0.0f;
+		const int *i_thp = nullptr, *i_bias = nullptr, *i_qself = nullptr;  // 8-bit logs: raw accumulators, scored by the gather
+		int i_mode = 0;
 	} pending_scatter;
 	GrowPtr<float> d_sample;         // [m][n_chunks][32] class maxima of the fp16 / int8 sample pass
 	GrowPtr<void> d_q_split;         // [m][2][dim] bf16 (or [m][dim] fp16)
@@ -684,6 +686,7 @@ int ensure_hit_logs(expann_index* h, uint32_t grid, int waves, size_t m, uint32_
 	h->pending_scatter.m = (uint32_t)m;
 	h->pending_scatter.theta = nullptr;
 	h->pending_scatter.key_mul = 0.0f;
+	h->pending_scatter.i_mode = 0;
 	return EXPANN_OK;
 }
 
@@ -698,7 +701,8 @@ void launch_gather_logs(expann_index* h, hipStream_t st) {
 	const uint32_t cpb = std::max<uint32_t>(1, (ps.n_chunks + want - 1) / want);
 	const uint32_t n_groups = (ps.n_chunks + cpb - 1) / cpb;
 	GatherLogParams gp{h->d_log.as<const uint4>(), h->d_log_cnt.as<const uint32_t>(), ps.log_cap, ps.n_chunks,
-	                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap, ps.theta, ps.key_mul};
+	                   ps.n_qtiles, ps.xcd_map, ps.m, n_groups, cpb, h->d_cnt, h->d_cand, ps.cap, ps.theta, ps.key_mul,
+	                   ps.i_thp, ps.i_bias, ps.i_qself, ps.i_mode};
 	hipLaunchKernelGGL(gather_logs_kernel, dim3(ps.n_qtiles * 4 * n_groups), dim3(kBlock), 0, st, gp);
 }
 
@@ -1033,6 +1037,10 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			if (rc != EXPANN_OK)
 				return rc;
 			wp.lost = h->d_overflow;
+			h->pending_scatter.i_thp = fp.thp;
+			h->pending_scatter.i_bias = fp.bias;
+			h->pending_scatter.i_qself = fp.qself;
+			h->pending_scatter.i_mode = fp.bias ? 1 : 2;
 		}
 		const bool timed = h->profiling && h->ev_used < kEventPairs;
 		if (timed)

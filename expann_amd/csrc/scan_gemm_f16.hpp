@@ -252,9 +252,17 @@ struct GatherLogParams {
 	uint32_t cap;
 	// fp16 logs (scan_gemm_f16x.hpp): an entry is {bits of bn' - acc, row, query}; the key is made HERE,
 	// make_key((x + theta[query]) * key_mul, row) -- the arithmetic the scan's flush used to do behind a second
-	// LDS round trip.  nullptr (scan_gemm_i8w.hpp): entries hold the finished key in x, y.
+	// LDS round trip.
 	const float* theta;
 	float key_mul;
+	// 8-bit logs (scan_gemm_i8w.hpp): an entry is {raw accumulator, row, query}; the exact integer score is made
+	// HERE -- dot = acc - i_thp[query], L2 forms: i_bias[row] - 2 dot + i_qself[query], inner product: -dot --
+	// instead of two global gathers per hit inside the MFMA kernel (whose vmcnt they shared with the stage
+	// loads).  i_mode: 0 = not an 8-bit log, 1 = L2 forms, 2 = inner product.
+	const int* i_thp;
+	const int* i_bias;
+	const int* i_qself;
+	int i_mode;
 };
 __global__ __launch_bounds__(kBlock) void gather_logs_kernel(GatherLogParams p) {
 	__shared__ uint32_t cnt[64], base[64];
@@ -295,10 +303,17 @@ __global__ __launch_bounds__(kBlock) void gather_logs_kernel(GatherLogParams p) 
 			const uint4 e = src[i];
 			const uint32_t ql = (e.z - q0) & 63;
 			const uint32_t slot = base[ql] + atomicAdd(&cnt[ql], 1u);
-			if (slot < p.cap)
-				p.cand[(size_t)e.z * p.cap + slot] =
-				    p.theta ? make_key((__builtin_bit_cast(float, e.x) + p.theta[e.z]) * p.key_mul, e.y)
-				            : ((uint64_t)e.y << 32) | e.x;
+			if (slot < p.cap) {
+				uint64_t key;
+				if (p.i_mode) {
+					const int dot = (int)e.x - p.i_thp[e.z];
+					const int score = p.i_mode == 1 ? p.i_bias[e.y] - 2 * dot + p.i_qself[e.z] : -dot;
+					key = make_key((float)score, e.y);
+				} else {
+					key = make_key((__builtin_bit_cast(float, e.x) + p.theta[e.z]) * p.key_mul, e.y);
+				}
+				p.cand[(size_t)e.z * p.cap + slot] = key;
+			}
 		}
 	}
 }

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	};
 	static_assert(sizeof(QEntry) == kF16EntryBytes, "queue entry size");
 	QEntry* const queue = reinterpret_cast<QEntry*>(bn_slots + NBUF * WAVES * 256) + wave * QCAP;
-	int* const thq = reinterpret_cast<int*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
-	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
+	// (behind the queues: WGQ words that held the queries' start values for the flush's scores until round 3)
+	uint32_t* const fills = reinterpret_cast<uint32_t*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes) + WGQ;
 
 	// query fragments: lane l holds query l & 15 of tile tq, chunk 4 s + (l >> 4) of its row
 	i32x4 a[4][KS];
@@ -111,8 +111,6 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
 			th[tq][r] = qi < p.m ? p.thp[qi] : kNever / 2;
 		}
-	if (tid < WGQ)
-		thq[tid] = wg_q0 + tid < p.m ? p.thp[wg_q0 + tid] : kNever / 2;
 #pragma unroll
 	for (int tq = 0; tq < 4; ++tq) {
 #pragma unroll
@@ -172,28 +170,33 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	uint4* const my_log = pw.log + ((size_t)blockIdx.x * WAVES + wave) * pw.log_cap;
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
-		for (uint32_t base = 0; base < n * 16; base += 64) {
-			const uint32_t i = base + lane;
-			const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
-			const uint32_t v = i & 15;
-			const int c = e.acc[v];
-			const uint32_t row = e.row;
-			const bool hit = i < n * 16 && c >= e.bp && row < p.n_rows;
-			const uint32_t qi = e.qrow0 + 16 * (v >> 2) + (v & 3);
-			const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-			if (mask == 0)
-				continue;
-			uint64_t key = 0;
-			if (hit) {
-				const int dot = c - thq[(qi - wg_q0) & (WGQ - 1)];
-				const int score = L2FORM ? p.bias[row] - 2 * dot + p.qself[qi] : -dot;
-				key = make_key((float)score, row);
+		// 16 lanes per entry, two rounds of 4 entries in flight; a log entry is {raw accumulator, row, query}:
+		// gather_logs_kernel makes the exact score (GatherLogParams::i_mode)
+		for (uint32_t base = 0; base < n * 16; base += 128) {
+			bool hit[2];
+			int cv[2];
+			uint32_t row[2], qi[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				const uint32_t i = base + 64 * u + lane;
+				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
+				const uint32_t v = i & 15;
+				cv[u] = e.acc[v];
+				row[u] = e.row;
+				hit[u] = i < n * 16 && cv[u] >= e.bp && row[u] < p.n_rows;
+				qi[u] = e.qrow0 + 16 * (v >> 2) + (v & 3);
 			}
-			const uint32_t pos = glog_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-			                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-			if (hit && pos < pw.log_cap)
-				my_log[pos] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), qi, 0u);
-			glog_n += (uint32_t)__builtin_popcountll(mask);
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit[u]);
+				if (mask == 0)
+					continue;
+				const uint32_t pos = glog_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+				                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+				if (hit[u] && pos < pw.log_cap)
+					my_log[pos] = make_uint4((uint32_t)cv[u], row[u], qi[u], 0u);
+				glog_n += (uint32_t)__builtin_popcountll(mask);
+			}
 		}
 		wfill = 0;
 	};
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	// ---- the pipeline: scan_gemm_f16x.hpp's step (ONE barrier, after tile column 1) ---------------
 	stage(t0, 0);
 	stage(t0 + 1, 1);
-	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles t0, t0+1 landed, thq visible
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles t0, t0+1 landed
 
 	i32x4 acc[4][4];
 	int buf = 0;
