@@ -147,13 +147,15 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		constexpr int R = 4;
+		uint32_t ln = (uint32_t)lane;
+		asm volatile("" : "+v"(ln));  // (opaque: the queue addresses are formed HERE, not held across the tile loop)
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
 			uint32_t qi[R], slot[R];
 			uint64_t key[R];
 #pragma unroll
 			for (int j = 0; j < R; ++j) {
-				const uint32_t i = base + j * 64 + lane;
+				const uint32_t i = base + j * 64 + ln;
 				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
 				const uint32_t v = i & 15;
 				const float c = e.acc[v & 7], bn = e.bn;
@@ -208,22 +210,30 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 	f32x4 acc[2][4];
 	int buf = 0, pbuf = PF;
 	uint32_t since_look = 0;
+	auto frag_of = [&](int b, int tc, int s) -> f16x8 {
+		return *reinterpret_cast<const f16x8*>(smem + ((uint32_t)b * TILE_BYTES + aoff[s & 3] + (s >> 2) * 256) + tc * 16 * ROWB);
+	};
+	auto read_bn = [&](float (&bn)[4], int b) {
+		const float* slot = reinterpret_cast<const float*>(bn_slots + (b * WAVES + wave) * 256);
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc)
+			bn[tc] = slot[tc * 16 + l15];
+	};
+	// The step (round 3, as scan_gemm_i8x.hpp): MFMAs of tile t -> barrier (tile t+1 landed) -> the first
+	// fragments of tile t+1 are REQUESTED -> epilogue of tile t while they travel -> MFMAs of tile t+1.
+	f16x8 fb0[4];  // k-step 0 of the tile about to be multiplied
+	float bv[4];
+#pragma unroll
+	for (int tc = 0; tc < 4; ++tc)
+		fb0[tc] = frag_of(0, tc, 0);
 	for (uint32_t t = t0; t < t1; ++t) {
-		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
-		auto frag = [&](int tc, int s) -> f16x8 {
-			return *reinterpret_cast<const f16x8*>(smem + (boff + aoff[s & 3] + (s >> 2) * 256) + tc * 16 * ROWB);
-		};
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
 		f16x8 fb[KS][4];
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
-			fb[0][tc] = frag(tc, 0);
-		const float* slot = reinterpret_cast<const float*>(bn_slots + (buf * WAVES + wave) * 256);
-		float bv[4];
-#pragma unroll
-		for (int tc = 0; tc < 4; ++tc)
-			bv[tc] = slot[tc * 16 + l15];
+			fb[0][tc] = fb0[tc];
+		read_bn(bv, buf);  // (SAMPLE: the MFMAs' C operand; else used by the epilogue behind the barrier)
 		f32x4 c0[4];  // SAMPLE: -bn' of this lane's row in every column
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 			if (s + 1 < KS) {  // one k-step (8 MFMAs, 128 cycles) ahead
 #pragma unroll
 				for (int tc = 0; tc < 4; ++tc)
-					fb[s + 1][tc] = frag(tc, s + 1);
+					fb[s + 1][tc] = frag_of(buf, tc, s + 1);
 			}
 #pragma unroll
 			for (int tq = 0; tq < 2; ++tq)
@@ -251,6 +261,15 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		__builtin_amdgcn_s_setprio(0);
+		const bool look = !SAMPLE && ++since_look == kF16FlushEvery;
+		if (look && lane == 0)
+			fills[wave] = wfill;
+		wait_vm_then_barrier<(PF - 1) * LOADS>();
+		const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc)
+			fb0[tc] = frag_of(nbuf, tc, 0);  // (past the last tile: its re-staged copy)
+		__builtin_amdgcn_sched_barrier(0);
 		if constexpr (SAMPLE) {
 #pragma unroll
 			for (int par = 0; par < 2; ++par)
@@ -259,11 +278,10 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 #pragma unroll
 					for (int r = 0; r < 4; ++r)
 						smax[par][tq][r] = max3f(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
-			wait_vm_then_barrier<(PF - 1) * LOADS>();
 		} else {
 			// one max tree + compare per 16-row column, one wave-uniform test per step
 			float gmax[4];
-	#pragma unroll
+#pragma unroll
 			for (int tc = 0; tc < 4; ++tc)
 				gmax[tc] = __builtin_fmaxf(max3f(acc[0][tc][0], acc[0][tc][1], acc[0][tc][2]),
 				                           max3f(acc[0][tc][3], acc[1][tc][0], max3f(acc[1][tc][1], acc[1][tc][2], acc[1][tc][3])));
@@ -279,19 +297,17 @@ __global__ __launch_bounds__(F16Geom<D>::THREADS, 2) void scan_gemm_f16y_kernel(
 			}
 			if (wfill >= (uint32_t)QCAP * 3 / 4)
 				flush_own();
-			const bool look = ++since_look == kF16FlushEvery;
-			if (look && lane == 0)
-				fills[wave] = wfill;
-			wait_vm_then_barrier<(PF - 1) * LOADS>();
 			if (look) {
 				since_look = 0;
-				const uint32_t f = fills[lane & (WAVES - 1)];
+				uint32_t ln = (uint32_t)lane;
+				asm volatile("" : "+v"(ln));  // (opaque, as in flush_own: one address register fewer across the tile loop)
+				const uint32_t f = fills[ln & (WAVES - 1)];
 				if (__builtin_amdgcn_ballot_w64(f >= (uint32_t)QCAP / 2) != 0)
 					flush_own();
 			}
 		}
 		pbuf = buf;
-		buf = buf + 1 == NBUF ? 0 : buf + 1;
+		buf = nbuf;
 	}
 	if constexpr (SAMPLE) {
 #pragma unroll

@@ -159,13 +159,15 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		constexpr int R = 8;
+		uint32_t ln = (uint32_t)lane;
+		asm volatile("" : "+v"(ln));  // (opaque: the queue addresses are formed HERE -- hoisted out of the tile loop they spilled at d = 960)
 		for (uint32_t base = 0; base < n * 16; base += 64 * R) {
 			bool hit[R];
 			uint32_t qi[R], slot[R], row[R];
 			int dot[R];
 #pragma unroll
 			for (int j = 0; j < R; ++j) {
-				const uint32_t i = base + j * 64 + lane;
+				const uint32_t i = base + j * 64 + ln;
 				const QEntry& e = queue[i < n * 16 ? i >> 4 : 0];
 				const uint32_t v = i & 15;
 				const int c = e.acc[v & 7];
@@ -225,22 +227,32 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	i32x4 acc[2][4];
 	int buf = 0, pbuf = PF;
 	uint32_t since_look = 0;
+	auto frag_of = [&](int b, int tc, int s) -> i32x4 {
+		return *reinterpret_cast<const i32x4*>(smem + ((uint32_t)b * TILE_BYTES + aoff[s & 3] + (s >> 2) * 256) + tc * 16 * ROWB);
+	};
+	auto read_bp = [&](int (&bp)[4], int b) {
+		const int* slot = reinterpret_cast<const int*>(bn_slots + (b * WAVES + wave) * 256);
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc)
+			bp[tc] = slot[tc * 16 + l15];
+	};
+	// The step (round 3): MFMAs of tile t -> barrier (tile t+1 landed) -> the first fragments and row terms of
+	// tile t+1 are REQUESTED -> epilogue of tile t (max trees, hit test, queue push) while they travel -> MFMAs of
+	// tile t+1.  Before, the epilogue sat in front of the barrier and every step began with an exposed LDS round
+	// trip, at the same moment in both waves of a SIMD (one workgroup per CU: they leave the barrier together).
+	i32x4 fb0[4];  // k-step 0 of the tile about to be multiplied
+	int bv[4];
+#pragma unroll
+	for (int tc = 0; tc < 4; ++tc)
+		fb0[tc] = frag_of(0, tc, 0);
 	for (uint32_t t = t0; t < t1; ++t) {
-		const uint32_t boff = (uint32_t)buf * TILE_BYTES;
-		auto frag = [&](int tc, int s) -> i32x4 {
-			return *reinterpret_cast<const i32x4*>(smem + (boff + aoff[s & 3] + (s >> 2) * 256) + tc * 16 * ROWB);
-		};
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
 		i32x4 fb[KS][4];
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
-			fb[0][tc] = frag(tc, 0);
-		const int* slot = reinterpret_cast<const int*>(bn_slots + (buf * WAVES + wave) * 256);
-		int bv[4];
-#pragma unroll
-		for (int tc = 0; tc < 4; ++tc)
-			bv[tc] = slot[tc * 16 + l15];
+			fb[0][tc] = fb0[tc];
+		read_bp(bv, buf);  // (used by the epilogue behind the barrier: the k-steps cover the read)
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 			if (s + 1 < KS) {  // one k-step (8 MFMAs, 128 cycles) ahead
 #pragma unroll
 				for (int tc = 0; tc < 4; ++tc)
-					fb[s + 1][tc] = frag(tc, s + 1);
+					fb[s + 1][tc] = frag_of(buf, tc, s + 1);
 			}
 #pragma unroll
 			for (int tq = 0; tq < 2; ++tq)
@@ -263,6 +275,15 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		__builtin_amdgcn_s_setprio(0);
+		const bool look = ++since_look == kF16FlushEvery;
+		if (look && lane == 0)
+			fills[wave] = wfill;
+		wait_vm_then_barrier<(PF - 1) * LOADS>();
+		const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc)
+			fb0[tc] = frag_of(nbuf, tc, 0);  // (past the last tile: its re-staged copy)
+		__builtin_amdgcn_sched_barrier(0);
 		// one max tree + compare per 16-row column, one wave-uniform test per step
 		int gmax[4];
 #pragma unroll
@@ -281,10 +302,6 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 		}
 		if (wfill >= (uint32_t)QCAP * 3 / 4)
 			flush_own();
-		const bool look = ++since_look == kF16FlushEvery;
-		if (look && lane == 0)
-			fills[wave] = wfill;
-		wait_vm_then_barrier<(PF - 1) * LOADS>();
 		if (look) {
 			since_look = 0;
 			const uint32_t f = fills[lane & (WAVES - 1)];
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 				flush_own();
 		}
 		pbuf = buf;
-		buf = buf + 1 == NBUF ? 0 : buf + 1;
+		buf = nbuf;
 	}
 	flush_own();
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
