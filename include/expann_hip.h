@@ -292,8 +292,8 @@ size_t expann_antitopo_size(const expann_antitopo* e);
 uint64_t expann_antitopo_num_distcomps(const expann_antitopo* e);
 
 /* test hook: replays a trace of priority-queue operations through the device's wave-cooperative heap code
- * (csrc/graph_search.hpp coop_push / coop_pop, the walk's queues) on device 0.  Same signature and output
- * format as the oracle's oracle_heap_trace: ops[i] 1 = push (op_d[i], op_id[i]), 0 = pop; entry 0 of the
+ * (csrc/graph_search.hpp coop_push / coop_pop, the walk's queues) on device 0.  Trace format of
+ * tests/golden/heap_ref.json: ops[i] 1 = push (op_d[i], op_id[i]), 0 = pop; entry 0 of the
  * out_* arrays is the state after the range constructor, entry i + 1 the state after op i; returns the
  * drain length, (size_t)-1 on failure.  tests/test_heap_pin.py checks it against the traces the image's
  * real std::priority_queue answered (tests/golden/heap_ref.json). */
