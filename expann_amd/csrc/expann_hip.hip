@@ -636,17 +636,22 @@ int ensure_bias_i8(expann_index* h, const GemmI8Variant* gv, hipStream_t st) {
 
 // one wave per query for lists of <= 512 keys, then (when the buffers allow longer lists) for
 // <= 1024 and <= 2048; select_topk_kernel takes what is left (sel.wave_done = longest list served)
-void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st) {
+// `expect` = the list length the thresholds aim at (~1.2 k frac): a stage whose lists would be the rare tail
+// is not launched -- an empty launch still costs ~5 us of the stream, 3 % of a step on a 125 k-row shard --
+// and select_topk_kernel's workgroup-per-query sort takes those few lists.
+void launch_select_wave(SelectParams& sel, size_t m, uint32_t cap, hipStream_t st, uint32_t expect) {
 	sel.wave_done = 0;
 	hipLaunchKernelGGL((select_wave_kernel<8, 4>), dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, sel,
 	                   (uint32_t)m);
 	sel.wave_done = 512;
+	if (expect <= 256)
+		return;
 	if (cap > 512) {
 		// (k = 100: ~920-entry lists -- half the registers and ballots of the 2048-key form)
 		hipLaunchKernelGGL((select_wave_kernel<16, 2>), dim3((uint32_t)((m + 1) / 2)), dim3(128), 0, st, sel, (uint32_t)m);
 		sel.wave_done = 1024;
 	}
-	if (cap > 1024) {
+	if (cap > 1024 && expect > 512) {
 		hipLaunchKernelGGL((select_wave_kernel<32, 1>), dim3((uint32_t)m), dim3(64), 0, st, sel, (uint32_t)m);
 		sel.wave_done = 2048;
 	}
@@ -1077,7 +1082,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		if (h->profiling)
 			hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, st, sel.cand_cnt, (uint32_t)m,
 			                   h->d_total);
-		launch_select_wave(sel, m, cap, st);
+		launch_select_wave(sel, m, cap, st, (uint32_t)(1.2 * (double)k * sample_frac_for(h, k)));
 		mark("select_wave");
 		hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock), sizeof(uint64_t) * cap + 16,
 		                   st, sel);
@@ -1809,7 +1814,7 @@ int SearchPass::run_level(size_t li) {
 		sel.wave0_short = 1;  // latency mode: one launch, wave 0 orders the short lists
 	} else if (sel.rerank_base && sel.cand_cnt) {
 		// short lists (the usual case after a GEMM-form scan): one wave per query
-		launch_select_wave(sel, m, cap, st);
+		launch_select_wave(sel, m, cap, st, (uint32_t)(1.2 * (double)k * sample_frac_for(h, k)));
 	}
 	hipLaunchKernelGGL(select_topk_kernel, dim3((uint32_t)m), dim3(kBlock),
 	                   sizeof(uint64_t) * cap + 16, st, sel);
