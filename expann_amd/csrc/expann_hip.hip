@@ -147,6 +147,7 @@ struct expann_index {
 	long opt_tail_chunks = 1;        // scan_gemm_f16x: the last round's row chunks three times finer (pick_tail_chunks)
 	long opt_persist = 1;            // scan_gemm_f16x: resident workgroups pull (query tile, row chunk) items per XCD
 	long opt_i8w = 1;                // 8-bit rows, d = 128 / 256: scan_gemm_i8w.hpp (16x16x64, f16x's step, hit logs)
+	long opt_i8w_sample = 1;         // their sampled pass on the same stream (0: scan_gemm_i8q_kernel<D, L2F, true>, for A/B runs)
 	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
 	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
@@ -827,6 +828,7 @@ struct GemmI8qVariant {
 	// scan_gemm_i8w.hpp: the full scan writes per-wave hit logs (gather_logs_kernel files them)
 	void (*scan_w)(GemmI8wParams) = nullptr;
 	int lds_w = 0, threads_w = 0, wg_per_cu_w = 0;
+	void (*sample_w)(GemmI8wParams) = nullptr;  // the sampled pass on the same stream (SAMPLE instance; same launch geometry)
 };
 #define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false, D>, \
 	scan_gemm_i8q_kernel<DQ, L2F, true, D>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
@@ -853,7 +855,8 @@ const GemmI8qVariant kGemmI8x[] = {
 // d = 128 / 256: f16x's step structure on 16x16x64 with hit logs (scan_gemm_i8w.hpp)
 #define GEMM_I8W(D, MODE, L2F, MN) {D, MODE, nullptr, scan_gemm_i8q_kernel<D, L2F, true>, row_self_i8_kernel<D, MODE>, \
 	query_theta_i8_kernel<D, MODE>, "scan_gemm_i8w<" #D "," MN ">", D, gemm_i8q_lds_bytes<D>(), kF16Threads, \
-	I8wGeom<D>::WG_PER_CU, scan_gemm_i8w_kernel<D, L2F>, gemm_i8w_lds_bytes<D>(), kF16Threads, I8wGeom<D>::WG_PER_CU}
+	I8wGeom<D>::WG_PER_CU, scan_gemm_i8w_kernel<D, L2F>, gemm_i8w_lds_bytes<D>(), kF16Threads, I8wGeom<D>::WG_PER_CU, \
+	scan_gemm_i8w_kernel<D, L2F, true>}
 const GemmI8qVariant kGemmI8w[] = {
     GEMM_I8W(128, kU8L2, true, "U8L2"), GEMM_I8W(128, kI8L2, true, "I8L2"), GEMM_I8W(128, kI8IP, false, "I8IP"),
     GEMM_I8W(256, kU8L2, true, "U8L2"), GEMM_I8W(256, kI8L2, true, "I8L2"), GEMM_I8W(256, kI8IP, false, "I8IP")};
@@ -960,7 +963,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 	const uint32_t run = (uint32_t)h->opt_sample_run;
 	const uint32_t t_sel = std::max<uint32_t>(256, nt / sample_frac_for(h, k)) / run * run;
 	const uint32_t nqt = (uint32_t)((m + kF16TQ - 1) / kF16TQ);
-	const uint32_t wg_slots = (uint32_t)gq->wg_per_cu * (uint32_t)cus;
+	const uint32_t wg_slots = (uint32_t)(gq->sample_w ? gq->wg_per_cu_w : gq->wg_per_cu) * (uint32_t)cus;
 	uint32_t chunks = std::max<uint32_t>(1, wg_slots / nqt);
 	chunks = std::max<uint32_t>(chunks, (uint32_t)((8 * k + 31) / 32));
 	chunks = std::min<uint32_t>(chunks, std::min<uint32_t>(64, t_sel / 4));
@@ -999,7 +1002,13 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			             schunks, nqt, t_sel, sp.tile_stride, sp.tiles_per_block, schunks, nt, m, sp.base,
 			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->d_sample.bytes);
 		mark("qself");
-		hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), wg, lds, st, sp);
+		if (gq->sample_w && h->opt_i8w_sample) {
+			GemmI8wParams wsp{};
+			wsp.q = sp;
+			hipLaunchKernelGGL(gq->sample_w, dim3(schunks * nqt), dim3((uint32_t)gq->threads_w), gq->lds_w, st, wsp);
+		} else {
+			hipLaunchKernelGGL(gq->sample, dim3(schunks * nqt), wg, lds, st, sp);
+		}
 		mark("sample");
 		SampleTauI8Params tp{};
 		tp.vals = h->d_sample.as<const int>();
@@ -2063,6 +2072,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		h->opt_i8x = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_I8W"))
 		h->opt_i8w = std::atol(e);
+	if (const char* e = std::getenv("EXPANN_I8W_SAMPLE"))
+		h->opt_i8w_sample = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_TAIL_CHUNKS"))
 		h->opt_tail_chunks = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_PERSIST"))
@@ -2109,7 +2120,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 		}
 	for (const auto& v : kGemmI8w)
 		if (v.d == dim &&
-		    hipFuncSetAttribute((const void*)v.scan_w, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_w) != hipSuccess) {
+		    (hipFuncSetAttribute((const void*)v.scan_w, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_w) != hipSuccess ||
+		     hipFuncSetAttribute((const void*)v.sample_w, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_w) != hipSuccess)) {
 			g_create_error = "hipFuncSetAttribute(scan_gemm_i8w_kernel) failed";
 			hipStreamDestroy(h->stream);
 			delete h;
@@ -2569,6 +2581,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_i8x = value;
 	else if (!std::strcmp(name, "i8w"))
 		h->opt_i8w = value;
+	else if (!std::strcmp(name, "i8w_sample"))
+		h->opt_i8w_sample = value;
 	else if (!std::strcmp(name, "tail_chunks"))
 		h->opt_tail_chunks = value;
 	else if (!std::strcmp(name, "persist"))

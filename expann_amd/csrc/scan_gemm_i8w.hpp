@@ -36,7 +36,13 @@ struct GemmI8wParams {
 	uint32_t* lost;
 };
 
-template <int D, bool L2FORM>
+// SAMPLE (round 3: the threshold pass on the same stream, as scan_gemm_f16x_kernel<D, true>): no thresholds, no
+// candidate path; a lane's accumulators of one tile column belong to ONE row, so the row term enters as the
+// MFMA's C operand -- they start at -bp -- and the epilogue is the running maximum of g = dot - bp per (query
+// register, row class), class = row mod 32 = 16 (column & 1) + lane & 15, the two columns of equal parity
+// folded by one v_max3.  A padding row's bp is 2^30: its g never wins.  Output: q.sample_out, the layout
+// sample_tau_i8_kernel reads ([(query * n_chunks + chunk) * 32 + class]).
+template <int D, bool L2FORM, bool SAMPLE = false>
 __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_i8w_kernel(GemmI8wParams pw) {
 	static_assert(D == 128 || D == 256, "built for d = 128, 256");
 	const GemmI8qParams& p = pw.q;
@@ -68,10 +74,15 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	uint32_t t1 = t0 + p.tiles_per_block;
 	if (t1 > p.n_tiles_sel)
 		t1 = p.n_tiles_sel;
-	uint32_t* const my_log_cnt = pw.log_cnt + (size_t)blockIdx.x * WAVES + wave;
+	uint32_t* const my_log_cnt = SAMPLE ? nullptr : pw.log_cnt + (size_t)blockIdx.x * WAVES + wave;
 	if (t0 >= t1) {
-		if (lane == 0)
+		if (SAMPLE) {  // (the host plans no empty chunk; if one appears its class maxima are "no row")
+			for (uint32_t i = lane; i < 64 * 32; i += 64)
+				if (q0 + (i >> 5) < p.m)
+					p.sample_out[((size_t)(q0 + (i >> 5)) * p.n_chunks + chunk) * 32 + (i & 31)] = kNever;
+		} else if (lane == 0) {
 			*my_log_cnt = 0;
+		}
 		return;
 	}
 
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
-			th[tq][r] = qi < p.m ? p.thp[qi] : kNever / 2;
+			th[tq][r] = (qi < p.m && !SAMPLE) ? p.thp[qi] : kNever / 2;
 		}
 #pragma unroll
 	for (int tq = 0; tq < 4; ++tq) {
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	// compacted 16-byte stores at a wave-uniform position -- to this wave's log in global memory
 	uint32_t wfill = 0;   // wave-uniform: entries in the LDS queue
 	uint32_t glog_n = 0;  // wave-uniform: entries in this wave's global log
-	uint4* const my_log = pw.log + ((size_t)blockIdx.x * WAVES + wave) * pw.log_cap;
+	uint4* const my_log = SAMPLE ? nullptr : pw.log + ((size_t)blockIdx.x * WAVES + wave) * pw.log_cap;
 	auto flush_own = [&]() {
 		const uint32_t n = wfill < (uint32_t)QCAP ? wfill : (uint32_t)QCAP;
 		// 16 lanes per entry, two rounds of 4 entries in flight; a log entry is {raw accumulator, row, query}:
@@ -255,16 +266,31 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 	};
 	// k-steps [s0, s1) of tile column tc; a column is issued as k-step 0, the NEXT column's fragment reads, the
 	// rest (scan_gemm_f16x.hpp: no lgkmcnt(0) in front of a column that exposes those reads' round trip)
+	int bpv[4];
+	i32x4 smax[2][4];  // SAMPLE: running class maxima of g
+#pragma unroll
+	for (int par = 0; par < 2; ++par)
+#pragma unroll
+		for (int tq = 0; tq < 4; ++tq)
+			smax[par][tq] = i32x4{kNever, kNever, kNever, kNever};
+	auto fold = [&](int par) {
+#pragma unroll
+		for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				smax[par][tq][r] = max3i(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
+	};
 	auto mfma_part = [&](int tc, const i32x4 (&f)[KS], int s0, int s1) {
+		const int nb = -bpv[tc];
+		const i32x4 c0 = {nb, nb, nb, nb};
 #pragma unroll
 		for (int s = s0; s < s1; ++s)
 #pragma unroll
 			for (int tq = 0; tq < 4; ++tq)
-				acc[tq][tc] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tq][s], f[s], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+				acc[tq][tc] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tq][s], f[s], s == 0 ? (SAMPLE ? c0 : th[tq]) : acc[tq][tc], 0, 0, 0);
 	};
 
 	i32x4 fb[2][KS];  // fragments of the column being multiplied / the next one
-	int bpv[4];
 #pragma unroll
 	for (int s = 0; s < KS; ++s)
 		fb[0][s] = frag_at(0, 0, s);
@@ -291,12 +317,14 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 			fb[0][s] = frag_at(buf, 2, s);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_part(1, fb[1], 1, KS);
-		gmax[0] = col_max(0);
-		asm volatile("" : "+v"(gmax[0]));  // (computed here, between column 1's MFMAs)
+		if (!SAMPLE) {
+			gmax[0] = col_max(0);
+			asm volatile("" : "+v"(gmax[0]));  // (computed here, between column 1's MFMAs)
+		}
 		__builtin_amdgcn_sched_barrier(0);
 		__builtin_amdgcn_s_setprio(0);
 		// ---- the step's barrier: tile t+1 landed, tile t-1 released ------------------------------
-		const bool look = ++since_look == kF16FlushEvery;
+		const bool look = !SAMPLE && ++since_look == kF16FlushEvery;
 		if (look && lane == 0)
 			fills[wave] = wfill;
 		asm volatile("" ::: "memory");
@@ -323,7 +351,8 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 #pragma unroll
 		for (int i = 0; i < (LOADS + 1) / 2; ++i)
 			stage_piece(stb, srow0, pbuf, i);
-		gmax[1] = col_max(1);
+		if (!SAMPLE)
+			gmax[1] = col_max(1);
 		__builtin_amdgcn_sched_barrier(0);
 		mfma_part(3, fb[1], 0, 1);
 		__builtin_amdgcn_sched_barrier(0);
@@ -336,33 +365,53 @@ __global__ __launch_bounds__(kF16Threads, I8wGeom<D>::WG_PER_CU) void scan_gemm_
 #pragma unroll
 		for (int i = (LOADS + 1) / 2; i < LOADS; ++i)
 			stage_piece(stb, srow0, pbuf, i);
-		gmax[2] = col_max(2);
+		if (SAMPLE)
+			fold(0);
+		else
+			gmax[2] = col_max(2);
 		__builtin_amdgcn_s_setprio(0);
-		gmax[3] = col_max(3);
-		// one wave-uniform test per step; the queue push is the rare path
-		const bool h0 = gmax[0] >= bpv[0], h1 = gmax[1] >= bpv[1], h2 = gmax[2] >= bpv[2], h3 = gmax[3] >= bpv[3];
-		if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {
-			const uint32_t row0 = tile_row0(t);
-			const unsigned long long k0 = __builtin_amdgcn_ballot_w64(h0), k1 = __builtin_amdgcn_ballot_w64(h1),
-			                         k2 = __builtin_amdgcn_ballot_w64(h2), k3 = __builtin_amdgcn_ballot_w64(h3);
-			if (k0) push_hits(acc, 0, k0, h0, bpv[0], row0);
-			if (k1) push_hits(acc, 1, k1, h1, bpv[1], row0);
-			if (k2) push_hits(acc, 2, k2, h2, bpv[2], row0);
-			if (k3) push_hits(acc, 3, k3, h3, bpv[3], row0);
+		if (SAMPLE) {
+			fold(1);
+		} else {
+			gmax[3] = col_max(3);
+			// one wave-uniform test per step; the queue push is the rare path
+			const bool h0 = gmax[0] >= bpv[0], h1 = gmax[1] >= bpv[1], h2 = gmax[2] >= bpv[2], h3 = gmax[3] >= bpv[3];
+			if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {
+				const uint32_t row0 = tile_row0(t);
+				const unsigned long long k0 = __builtin_amdgcn_ballot_w64(h0), k1 = __builtin_amdgcn_ballot_w64(h1),
+				                         k2 = __builtin_amdgcn_ballot_w64(h2), k3 = __builtin_amdgcn_ballot_w64(h3);
+				if (k0) push_hits(acc, 0, k0, h0, bpv[0], row0);
+				if (k1) push_hits(acc, 1, k1, h1, bpv[1], row0);
+				if (k2) push_hits(acc, 2, k2, h2, bpv[2], row0);
+				if (k3) push_hits(acc, 3, k3, h3, bpv[3], row0);
+			}
+			if (wfill >= (uint32_t)QCAP * 3 / 4)
+				flush_own();
 		}
-		if (wfill >= (uint32_t)QCAP * 3 / 4)
-			flush_own();
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): tile t+1's first fragments and row terms, requested under column 3
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			bpv[tc] = bpn[tc];
 		buf = nbuf;
 	}
-	flush_own();
-	if (lane == 0) {
-		*my_log_cnt = glog_n;
-		if (glog_n > pw.log_cap)  // (the log is as large as this wave's share of the candidate lists)
-			atomicAdd(pw.lost, 1u);
+	if (SAMPLE) {
+#pragma unroll
+		for (int par = 0; par < 2; ++par)
+#pragma unroll
+			for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
+					if (qi < p.m)
+						p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + par * 16 + l15] = smax[par][tq][r];
+				}
+	} else {
+		flush_own();
+		if (lane == 0) {
+			*my_log_cnt = glog_n;
+			if (glog_n > pw.log_cap)  // (the log is as large as this wave's share of the candidate lists)
+				atomicAdd(pw.lost, 1u);
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-staged tail tiles: LDS must outlive them
 }
