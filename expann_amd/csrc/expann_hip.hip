@@ -843,7 +843,7 @@ const GemmI8qVariant kGemmI8q[] = {
 // the 16x16x64 form of the full scan for the 8-waves-per-tile geometries (scan_gemm_i8x.hpp); the
 // sampled pass stays scan_gemm_i8q_kernel<DQ, L2F, true>
 #define GEMM_I8X_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8x_kernel<DQ, L2F, D>, \
-	scan_gemm_i8q_kernel<DQ, L2F, true, D>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
+	scan_gemm_i8x_kernel<DQ, L2F, D, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
 	"scan_gemm_i8x<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
 const GemmI8qVariant kGemmI8x[] = {
     GEMM_I8X_P(768, 768, kU8L2, true, "U8L2"), GEMM_I8X_P(768, 768, kI8L2, true, "I8L2"), GEMM_I8X_P(768, 768, kI8IP, false, "I8IP"),
@@ -2112,7 +2112,8 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 			}
 	for (const auto& v : kGemmI8x)
 		if (v.d == dim &&
-		    hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess) {
+		    (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess ||
+		     hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds) != hipSuccess)) {
 			g_create_error = "hipFuncSetAttribute(scan_gemm_i8x_kernel) failed";
 			hipStreamDestroy(h->stream);
 			delete h;

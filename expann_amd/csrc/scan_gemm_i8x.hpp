@@ -19,7 +19,12 @@
 namespace expann {
 
 // DR: bytes of a row slot that hold data (scan_gemm_i8q_kernel): 13 / 15 of the 16 k-steps at d = 832 / 960
-template <int D, bool L2FORM, int DR = D>
+// SAMPLE (round 3: the threshold pass on the same stream, as scan_gemm_i8w_kernel<D, L2F, true>): a lane's
+// accumulators of one tile column belong to ONE row, so they start at -bp (the MFMA's C operand) and the
+// epilogue is the running maximum of g = dot - bp per (query register, row class = row mod 32), the two columns of
+// equal parity folded by one v_max3; the row terms of tile t+1 are requested behind the barrier with its first
+// fragments.  Output: p.sample_out in sample_tau_i8_kernel's layout.
+template <int D, bool L2FORM, int DR = D, bool SAMPLE = false>
 __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(GemmI8qParams p) {
 	static_assert(D == 768 || D == 1024, "the 8-waves-per-tile geometry of scan_gemm_i8q.hpp");
 	static_assert(DR <= D && DR % 64 == 0, "whole k-steps of data");
@@ -52,8 +57,15 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	uint32_t t1 = t0 + p.tiles_per_block;
 	if (t1 > p.n_tiles_sel)
 		t1 = p.n_tiles_sel;
-	if (t0 >= t1)
+	constexpr int kNever = -2147483647 - 1;
+	if (t0 >= t1) {
+		if (SAMPLE) {  // (the host plans no empty chunk; if one appears its class maxima are "no row")
+			for (uint32_t i = lane; i < 32 * 32; i += 64)
+				if (q0 + (i >> 5) < p.m)
+					p.sample_out[((size_t)(q0 + (i >> 5)) * p.n_chunks + chunk) * 32 + (i & 31)] = kNever;
+		}
 		return;
+	}
 
 	unsigned char* const bn_slots = smem + NBUF * TILE_BYTES;
 	struct QEntry {
@@ -68,7 +80,6 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	int* const thq = reinterpret_cast<int*>(bn_slots + NBUF * WAVES * 256 + WAVES * QCAP * kF16EntryBytes);
 	uint32_t* const fills = reinterpret_cast<uint32_t*>(thq + WGQ);
 
-	constexpr int kNever = -2147483647 - 1;
 	i32x4 a[2][KS];
 #pragma unroll
 	for (int tq = 0; tq < 2; ++tq) {
@@ -86,9 +97,9 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
-			th[tq][r] = qi < p.m ? p.thp[qi] : kNever / 2;  // a padded query slot never reaches a bp >= 0
+			th[tq][r] = (qi < p.m && !SAMPLE) ? p.thp[qi] : kNever / 2;  // a padded query slot never reaches a bp >= 0
 		}
-	if (tid < WGQ)
+	if (!SAMPLE && tid < WGQ)
 		thq[tid] = wg_q0 + tid < p.m ? p.thp[wg_q0 + tid] : kNever / 2;
 #pragma unroll
 	for (int tq = 0; tq < 2; ++tq) {
@@ -241,10 +252,18 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 	// tile t+1.  Before, the epilogue sat in front of the barrier and every step began with an exposed LDS round
 	// trip, at the same moment in both waves of a SIMD (one workgroup per CU: they leave the barrier together).
 	i32x4 fb0[4];  // k-step 0 of the tile about to be multiplied
-	int bv[4];
+	int bv[4], bvn[4];
+	i32x4 smax[2][2];  // SAMPLE: running class maxima of g
+#pragma unroll
+	for (int par = 0; par < 2; ++par)
+#pragma unroll
+		for (int tq = 0; tq < 2; ++tq)
+			smax[par][tq] = i32x4{kNever, kNever, kNever, kNever};
 #pragma unroll
 	for (int tc = 0; tc < 4; ++tc)
 		fb0[tc] = frag_of(0, tc, 0);
+	if (SAMPLE)
+		read_bp(bvn, 0);
 	for (uint32_t t = t0; t < t1; ++t) {
 		uint32_t srow0;
 		const unsigned char* stb = stage_src(t + PF, srow0);
@@ -252,7 +271,14 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			fb[0][tc] = fb0[tc];
-		read_bp(bv, buf);  // (used by the epilogue behind the barrier: the k-steps cover the read)
+		i32x4 c0[4];  // SAMPLE: -bp of this lane's row in every column
+		if (SAMPLE) {
+#pragma unroll
+			for (int tc = 0; tc < 4; ++tc)
+				c0[tc] = i32x4{-bvn[tc], -bvn[tc], -bvn[tc], -bvn[tc]};
+		} else {
+			read_bp(bv, buf);  // (used by the epilogue behind the barrier: the k-steps cover the read)
+		}
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -266,7 +292,8 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 			for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
 				for (int tc = 0; tc < 4; ++tc)
-					acc[tq][tc] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tq][s], fb[s][tc], s == 0 ? th[tq] : acc[tq][tc], 0, 0, 0);
+					acc[tq][tc] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tq][s], fb[s][tc],
+					                                                    s == 0 ? (SAMPLE ? c0[tc] : th[tq]) : acc[tq][tc], 0, 0, 0);
 			constexpr int PER = (LOADS + KS - 1) / KS;
 #pragma unroll
 			for (int j = 0; j < PER; ++j)
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		__builtin_amdgcn_s_setprio(0);
-		const bool look = ++since_look == kF16FlushEvery;
+		const bool look = !SAMPLE && ++since_look == kF16FlushEvery;
 		if (look && lane == 0)
 			fills[wave] = wfill;
 		wait_vm_then_barrier<(PF - 1) * LOADS>();
@@ -283,7 +310,21 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 #pragma unroll
 		for (int tc = 0; tc < 4; ++tc)
 			fb0[tc] = frag_of(nbuf, tc, 0);  // (past the last tile: its re-staged copy)
+		if (SAMPLE)
+			read_bp(bvn, nbuf);
 		__builtin_amdgcn_sched_barrier(0);
+		if constexpr (SAMPLE) {
+#pragma unroll
+			for (int par = 0; par < 2; ++par)
+#pragma unroll
+				for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						smax[par][tq][r] = max3i(smax[par][tq][r], acc[tq][par][r], acc[tq][par + 2][r]);
+			pbuf = buf;
+			buf = nbuf;
+			continue;
+		}
 		// one max tree + compare per 16-row column, one wave-uniform test per step
 		int gmax[4];
 #pragma unroll
@@ -311,7 +352,20 @@ __global__ __launch_bounds__(I8qGeom<D>::THREADS, 2) void scan_gemm_i8x_kernel(G
 		pbuf = buf;
 		buf = nbuf;
 	}
-	flush_own();
+	if constexpr (SAMPLE) {
+#pragma unroll
+		for (int par = 0; par < 2; ++par)
+#pragma unroll
+			for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const uint32_t qi = q0 + tq * 16 + 4 * lq + r;
+					if (qi < p.m)
+						p.sample_out[((size_t)qi * p.n_chunks + chunk) * 32 + par * 16 + l15] = smax[par][tq][r];
+				}
+	} else {
+		flush_own();
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
