@@ -146,10 +146,6 @@ struct expann_index {
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_tail_chunks = 1;        // scan_gemm_f16x: the last round's row chunks three times finer (pick_tail_chunks)
 	long opt_persist = 1;            // scan_gemm_f16x: resident workgroups pull (query tile, row chunk) items per XCD
-	long opt_i8w = 1;                // 8-bit rows, d = 128 / 256: scan_gemm_i8w.hpp (16x16x64, f16x's step, hit logs)
-	long opt_i8w_sample = 1;         // their sampled pass on the same stream (0: scan_gemm_i8q_kernel<D, L2F, true>, for A/B runs)
-	long opt_i8x = 1;                // 8-bit rows, d >= 768: the 16x16x64 form of the full scan (scan_gemm_i8x.hpp)
-	long opt_f16x = 1;               // auto choice prefers the 16x16x32 form of the fp16 scan where built
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
@@ -830,18 +826,8 @@ struct GemmI8qVariant {
 	int lds_w = 0, threads_w = 0, wg_per_cu_w = 0;
 	void (*sample_w)(GemmI8wParams) = nullptr;  // the sampled pass on the same stream (SAMPLE instance; same launch geometry)
 };
-#define GEMM_I8Q_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8q_kernel<DQ, L2F, false, D>, \
-	scan_gemm_i8q_kernel<DQ, L2F, true, D>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
-	"scan_gemm_i8q<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
-#define GEMM_I8Q(D, MODE, L2F, MN) GEMM_I8Q_P(D, D, MODE, L2F, MN)
-const GemmI8qVariant kGemmI8q[] = {
-    GEMM_I8Q(128, kU8L2, true, "U8L2"), GEMM_I8Q(128, kI8L2, true, "I8L2"), GEMM_I8Q(128, kI8IP, false, "I8IP"),
-    GEMM_I8Q(256, kU8L2, true, "U8L2"), GEMM_I8Q(256, kI8L2, true, "I8L2"), GEMM_I8Q(256, kI8IP, false, "I8IP"),
-    GEMM_I8Q(768, kU8L2, true, "U8L2"), GEMM_I8Q(768, kI8L2, true, "I8L2"), GEMM_I8Q(768, kI8IP, false, "I8IP")};
-// (d = 832 / 960 -- rows in 1024-byte slots -- have the 16x16x64 full scan only: kGemmI8x below; their
-// sampled pass is scan_gemm_i8q_kernel<1024, L2F, true, d>)
-// the 16x16x64 form of the full scan for the 8-waves-per-tile geometries (scan_gemm_i8x.hpp); the
-// sampled pass stays scan_gemm_i8q_kernel<DQ, L2F, true>
+// the 16x16x64 kernels of the 8-waves-per-tile geometries (scan_gemm_i8x.hpp): d = 768, and d = 832 / 960 -- rows in
+// 1024-byte slots -- with DR = d (the zero-padded k-steps are left out); scan and SAMPLE instance
 #define GEMM_I8X_P(D, DQ, MODE, L2F, MN) {D, MODE, scan_gemm_i8x_kernel<DQ, L2F, D>, \
 	scan_gemm_i8x_kernel<DQ, L2F, D, true>, row_self_i8_kernel<D, MODE>, query_theta_i8_kernel<D, MODE>, \
 	"scan_gemm_i8x<" #DQ "," MN ">", DQ, gemm_i8q_lds_bytes<DQ>(), I8qGeom<DQ>::THREADS, I8qGeom<DQ>::WG_PER_CU}
@@ -853,7 +839,7 @@ const GemmI8qVariant kGemmI8x[] = {
     GEMM_I8X_P(960, 1024, kI8IP, false, "I8IP")};
 #undef GEMM_I8X_P
 // d = 128 / 256: f16x's step structure on 16x16x64 with hit logs (scan_gemm_i8w.hpp)
-#define GEMM_I8W(D, MODE, L2F, MN) {D, MODE, nullptr, scan_gemm_i8q_kernel<D, L2F, true>, row_self_i8_kernel<D, MODE>, \
+#define GEMM_I8W(D, MODE, L2F, MN) {D, MODE, nullptr, nullptr, row_self_i8_kernel<D, MODE>, \
 	query_theta_i8_kernel<D, MODE>, "scan_gemm_i8w<" #D "," MN ">", D, gemm_i8q_lds_bytes<D>(), kF16Threads, \
 	I8wGeom<D>::WG_PER_CU, scan_gemm_i8w_kernel<D, L2F>, gemm_i8w_lds_bytes<D>(), kF16Threads, I8wGeom<D>::WG_PER_CU, \
 	scan_gemm_i8w_kernel<D, L2F, true>}
@@ -861,8 +847,6 @@ const GemmI8qVariant kGemmI8w[] = {
     GEMM_I8W(128, kU8L2, true, "U8L2"), GEMM_I8W(128, kI8L2, true, "I8L2"), GEMM_I8W(128, kI8IP, false, "I8IP"),
     GEMM_I8W(256, kU8L2, true, "U8L2"), GEMM_I8W(256, kI8L2, true, "I8L2"), GEMM_I8W(256, kI8IP, false, "I8IP")};
 #undef GEMM_I8W
-#undef GEMM_I8Q
-#undef GEMM_I8Q_P
 constexpr int kRetryGeneric = -1000;  // internal: the caller falls back to the threshold ladder
 constexpr int kStrictReject = -1001;  // internal (uint8 shadow): these queries are not 8-bit integers
 
@@ -873,15 +857,10 @@ const GemmI8qVariant* pick_gemm_i8q(const expann_index* h, size_t m, size_t k) {
 		return nullptr;
 	if (h->n < 2 * 256 * kF16TB || k > 256)
 		return nullptr;
-	if (h->opt_i8w)
-		for (const auto& v : kGemmI8w)
-			if (v.d == h->dim && v.mode == h->int_mode)
-				return &v;
-	if (h->opt_i8x)
-		for (const auto& v : kGemmI8x)
-			if (v.d == h->dim && v.mode == h->int_mode)
-				return &v;
-	for (const auto& v : kGemmI8q)
+	for (const auto& v : kGemmI8w)
+		if (v.d == h->dim && v.mode == h->int_mode)
+			return &v;
+	for (const auto& v : kGemmI8x)
 		if (v.d == h->dim && v.mode == h->int_mode)
 			return &v;
 	return nullptr;
@@ -1002,7 +981,7 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 			             schunks, nqt, t_sel, sp.tile_stride, sp.tiles_per_block, schunks, nt, m, sp.base,
 			             (const void*)sp.bp, sp.queries, (void*)sp.sample_out, h->d_sample.bytes);
 		mark("qself");
-		if (gq->sample_w && h->opt_i8w_sample) {
+		if (gq->sample_w) {
 			GemmI8wParams wsp{};
 			wsp.q = sp;
 			hipLaunchKernelGGL(gq->sample_w, dim3(schunks * nqt), dim3((uint32_t)gq->threads_w), gq->lds_w, st, wsp);
@@ -1032,12 +1011,8 @@ int search_i8q(expann_index* h, const GemmI8qVariant* gq, const void* d_queries,
 		fp.cand_cnt = h->d_cnt;
 		fp.cand = h->d_cand;
 		fp.cap = cap;
-		// (a retry after overflowed logs / lists goes to the direct appends of scan_gemm_i8q)
+		// (a retry after overflowed logs / lists stays on the same kernel: the logs grow with the lists)
 		const GemmI8qVariant* gs = gq;
-		if (gq->scan_w && attempt > 0)
-			for (const auto& v : kGemmI8q)
-				if (v.d == gq->d && v.mode == gq->mode)
-					gs = &v;
 		const uint32_t scan_slots = gs->scan_w ? (uint32_t)gs->wg_per_cu_w * (uint32_t)cus : wg_slots;
 		uint32_t fchunks = pick_row_chunks(nt, nqt, scan_slots, 4.0, 8, 2048, h->opt_xcd_tolerance,
 		                                   (h->opt_debug & 1024) ? nullptr : &fp.xcd_map);
@@ -2066,14 +2041,6 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 	h->elem = (dtype == EXPANN_DTYPE_F32) ? 4 : (dtype == EXPANN_DTYPE_I16 ? 2 : 1);
 	h->q_elem = (dtype == EXPANN_DTYPE_I8) ? 1 : (dtype == EXPANN_DTYPE_I16 ? 2 : 4);
 	h->int_mode = int_mode;
-	if (const char* e = std::getenv("EXPANN_F16X"))  // A/B switches of the scans' MFMA shape (tests, bench)
-		h->opt_f16x = std::atol(e);
-	if (const char* e = std::getenv("EXPANN_I8X"))
-		h->opt_i8x = std::atol(e);
-	if (const char* e = std::getenv("EXPANN_I8W"))
-		h->opt_i8w = std::atol(e);
-	if (const char* e = std::getenv("EXPANN_I8W_SAMPLE"))
-		h->opt_i8w_sample = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_TAIL_CHUNKS"))
 		h->opt_tail_chunks = std::atol(e);
 	if (const char* e = std::getenv("EXPANN_PERSIST"))
@@ -2128,17 +2095,6 @@ int expann_create(int dim, int dtype, int metric, int device, expann_index** out
 			delete h;
 			return EXPANN_ERR_HIP;
 		}
-	for (const auto& v : kGemmI8q)
-		if (v.d == dim)
-			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        v.lds) != hipSuccess ||
-			    hipFuncSetAttribute((const void*)v.sample, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                        v.lds) != hipSuccess) {
-				g_create_error = "hipFuncSetAttribute(scan_gemm_i8q_kernel) failed";
-				hipStreamDestroy(h->stream);
-				delete h;
-				return EXPANN_ERR_HIP;
-			}
 	for (const auto& v : kGemmBf16)
 		if (v.d == dim)
 			if (hipFuncSetAttribute((const void*)v.scan, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2576,14 +2532,11 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_debug = value;
 	else if (!std::strcmp(name, "scan_kernel"))
 		h->opt_scan_kernel = value;
-	else if (!std::strcmp(name, "f16x"))
-		h->opt_f16x = value;
-	else if (!std::strcmp(name, "i8x"))
-		h->opt_i8x = value;
-	else if (!std::strcmp(name, "i8w"))
-		h->opt_i8w = value;
-	else if (!std::strcmp(name, "i8w_sample"))
-		h->opt_i8w_sample = value;
+	else if (!std::strcmp(name, "f16x") || !std::strcmp(name, "i8x") || !std::strcmp(name, "i8w")) {
+		// (rounds 1-2: A/B switches between the 32x32 kernels and the 16x16 ones; the 32x32 kernels are gone)
+		if (value == 0)
+			return h->fail(EXPANN_ERR_UNSUPPORTED, std::string(name) + " = 0: the 32 x 32 MFMA forms of rounds 1-2 were removed in round 3");
+	}
 	else if (!std::strcmp(name, "tail_chunks"))
 		h->opt_tail_chunks = value;
 	else if (!std::strcmp(name, "persist"))

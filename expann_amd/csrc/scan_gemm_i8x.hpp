@@ -1,8 +1,8 @@
 // scan_gemm_i8x.hpp -- the full scan of scan_gemm_i8q.hpp's 8-waves-per-tile geometry (d = 768: BASELINE
 // C5; d = 1024: the padded rows of d = 832 / 960 indexes) on v_mfma_i32_16x16x64_i8.
 //
-// Same g-domain arithmetic, parameters, LDS map, staging (counted vmcnt waits, two tile buffers) and
-// hit queues as scan_gemm_i8q_kernel<D, L2FORM, false>; what differs is the MFMA shape.  Measured on
+// The g-domain arithmetic, parameters, LDS map, staging (counted vmcnt waits, two tile buffers) and hit
+// queues of scan_gemm_i8q.hpp (rounds 1-2 ran them on v_mfma_i32_32x32x32_i8: removed in round 3).  Measured on
 // the fp16 filter (scan_gemm_f16x.hpp): under a dense MFMA stream the chip holds a
 // higher clock on the 16 x 16 shapes than on 32 x 32 at equal cycles per operation, and at d = 768 a
 // step is 96 % MFMA issue, so the clock is what is left to win.  With 16 x 16 tiles the base row sits
@@ -11,14 +11,13 @@
 //
 // A = queries: lane l holds query l & 15 of tile tq, 16-byte chunk 4 s + (l >> 4) of its row (k-step
 // s = 64 bytes); B = base rows from LDS: row l & 15 of column tc, same chunk; C: lane l, register r
-// = query 4 (l >> 4) + r of tile tq against row l & 15 of column tc.  The sampled pass keeps
-// scan_gemm_i8q_kernel<D, L2FORM, true>.
+// = query 4 (l >> 4) + r of tile tq against row l & 15 of column tc.
 #pragma once
 #include "scan_gemm_i8q.hpp"
 
 namespace expann {
 
-// DR: bytes of a row slot that hold data (scan_gemm_i8q_kernel): 13 / 15 of the 16 k-steps at d = 832 / 960
+// DR: bytes of a row slot that hold data: 13 / 15 of the 16 k-steps at d = 832 / 960 (the rest multiply zeros)
 // SAMPLE (round 3: the threshold pass on the same stream, as scan_gemm_i8w_kernel<D, L2F, true>): a lane's
 // accumulators of one tile column belong to ONE row, so they start at -bp (the MFMA's C operand) and the
 // epilogue is the running maximum of g = dot - bp per (query register, row class = row mod 32), the two columns of

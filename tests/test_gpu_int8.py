@@ -169,26 +169,18 @@ def test_gemm_form_int8_queues(oracle, dtype, metric, ometric, d, n, m, k):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,metric,ometric,d", [("u8", "l2", "METRIC_L2_U8", 128), ("i8", "ip", "METRIC_IP_I8", 128),
-                                                     ("i8", "l2", "METRIC_L2_I8", 256), ("u8", "l2", "METRIC_L2_U8", 768)])
-def test_gemm_form_int8_32x32_kernels(oracle, dtype, metric, ometric, d):
-    """options i8w = 0 / i8x = 0: round 1's 32x32x32 kernels (scan_gemm_i8q) stay selectable and exact"""
-    i8w, kernel = 0, "scan_gemm_i8q"
-    n, m, k = 70001, 300, 17
-    rng = np.random.RandomState(d + 5)
-    if dtype == "u8":
-        base = _sift_like(rng, n, d).astype(np.uint8)
-        queries = _sift_like(rng, m, d).astype(np.float32)
-    else:
-        base = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
-        queries = rng.randint(-128, 128, size=(m, d)).astype(np.int8)
-    eng = _engine(base, metric, dtype)
-    eng.set_option("scan_kernel", 5)
-    eng.set_option("i8w", i8w)
-    eng.set_option("i8x", 0)
-    eng.set_profiling(True)
-    _check(oracle, eng, base, queries, k, getattr(oracle, ometric))
-    assert eng.get_profile()["scan_kernel"].startswith(kernel), eng.get_profile()["scan_kernel"]
+@pytest.mark.parametrize("opt", ["i8w", "i8x", "f16x"])
+def test_removed_32x32_forms_are_refused_loudly(opt):
+    """round 3 deleted the 32x32 MFMA kernels of rounds 1-2 (scan_gemm_i8q / scan_gemm_f16 / f16k): the options
+    that selected them (i8w = 0, i8x = 0, f16x = 0) fail instead of silently running something else; = 1 is
+    accepted (it is what runs)."""
+    rng = np.random.RandomState(3)
+    base = rng.randint(0, 256, size=(5000, 128)).astype(np.uint8)
+    eng = _engine(base, "l2", "u8")
+    eng.set_option(opt, 1)
+    with pytest.raises(Exception) as ei:
+        eng.set_option(opt, 0)
+    assert "removed in round 3" in str(ei.value)
     eng.close()
 
 
@@ -202,7 +194,8 @@ def test_int8_queues_overflow_retries(oracle):
     eng.set_profiling(True)
     _check(oracle, eng, base, queries, 10, oracle.METRIC_L2_U8)
     prof = eng.get_profile()
-    assert prof["scan_kernel"].startswith("scan_gemm_i8q") and prof["retries"] >= 1
+    # (the retry stays on the hit-log kernel: the logs grow with the lists)
+    assert prof["scan_kernel"].startswith("scan_gemm_i8w") and prof["retries"] >= 1
     eng.close()
 
 
