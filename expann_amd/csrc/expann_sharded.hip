@@ -506,7 +506,10 @@ int phase_wait(expann_sharded* h, int r) {
 int for_shards(expann_sharded* h, const std::function<int(int)>& fn) {
 	const int G = h->n_active;
 	int bad = EXPANN_OK, bad_r = -1;
-	const bool threaded = h->opt_threads != 0 && G > 1;
+	// (RCCL transport: always the shards' own threads.  One thread that calls a collective rank by rank
+	// without a group around all of them can block in the first rank's call until its peers join; a group around
+	// phase_exchange would defer the sends past the merge kernels enqueued inside it.)
+	const bool threaded = (h->opt_threads != 0 || h->exchange_used == 1) && G > 1;
 	for (int r = 0; r < G; ++r) {
 		Shard& s = h->shards[(size_t)r];
 		if (threaded) {
