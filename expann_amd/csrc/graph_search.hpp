@@ -140,6 +140,8 @@ __device__ inline void wave_lds_sync() {  // lanes exchange data through LDS: ke
 // std::__push_heap(first, hole, top = 0, value): lane j reads the j-th ancestor of the hole; the value
 // stops in front of the first ancestor that is not "less" than it; the ancestors below move down one.
 template <bool MAXH> __device__ inline void coop_push_up(md_pair* v, uint32_t hole, md_pair value, int lane) {
+	asm volatile("" : "+v"(lane));  // (opaque: the lanes' heap addresses are formed here -- hoisted out of the hop loop they
+	                                // spilled in the 128-register uint8 instance, a scratch round trip per queue update)
 	const uint32_t h1 = hole + 1;
 	const int levels = 31 - __builtin_clz(h1);  // ancestors of the hole
 	const bool act = lane < levels;
@@ -176,6 +178,7 @@ template <bool MAXH> __device__ inline void coop_push(md_pair* v, uint32_t& n, m
 // the chain's element t + 1, a ballot finds where the value settles.
 template <bool MAXH, int NPL>
 __device__ inline void coop_adjust(md_pair* v, uint32_t len, md_pair value, int lane) {
+	asm volatile("" : "+v"(lane));  // (opaque, as in coop_push_up)
 	const uint32_t half = (len - 1) / 2;  // nodes < half have two children
 	uint32_t big[NPL];
 #pragma unroll
@@ -350,7 +353,7 @@ template <int D> constexpr int graph_rows_u8() { return D <= 128 ? 16 : (D <= 25
 
 // (the uint8 walk waits on latency, not bandwidth: 128 registers = 16 waves per CU instead of 12)
 template <int D, bool COMPRESSED, int DBG = 0>
-__global__ __launch_bounds__(64, (COMPRESSED && D <= 256) ? 4 : 1) void graph_search_kernel(GraphSearchParams p) {
+__global__ __launch_bounds__(64, (COMPRESSED && D <= 128) ? 4 : 1) void graph_search_kernel(GraphSearchParams p) {
 	constexpr int DPL = D / 16;
 	constexpr int NW = D / 64;
 	unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts = DBG ? clock64() : 0;
