@@ -1820,6 +1820,13 @@ int SearchPass::check(int attempt, Next* next) {
 	unsigned long long tot;
 	std::memcpy(&tot, h->h_flags + 4, sizeof(tot));
 	h->prof.candidates = tot;
+	if (std::getenv("EXPANN_DEBUG_LISTS")) {  // (diagnostics: the distribution of the candidate lists' lengths)
+		std::vector<uint32_t> cnt(m);
+		HIP_TRY(h, hipMemcpy(cnt.data(), h->d_cnt, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+		std::sort(cnt.begin(), cnt.end());
+		std::fprintf(stderr, "[lists] attempt %d cap %u: min %u median %u p90 %u p99 %u max %u, overflow flag %u\n", attempt, cap,
+		             cnt.front(), cnt[m / 2], cnt[m * 9 / 10], cnt[m * 99 / 100], cnt.back(), h->h_flags[0]);
+	}
 	if (gvf) {  // queries outside the fp16 range of this index: redo with the bf16x3 form
 		float qmax;  // bit pattern of max |q| (flags word 2, read back with the overflow flags)
 		std::memcpy(&qmax, &h->h_flags[2], sizeof(float));
