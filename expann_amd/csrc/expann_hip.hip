@@ -116,7 +116,8 @@ struct expann_index {
 	DevPtr<void> d_base_f16;         // [n][dim] fp16 rows scaled by f16_scale (fp16 GEMM form), lazily
 	DevPtr<float> d_bnorm_f16;       // [n] ||b||^2 (1-eps) - abs |b|
 	DevPtr<float> d_bns_f16;         // [n] ||b||^2 (1+eps) + abs |b|: the sampled pass's row term
-	DevPtr<float> d_qnrm;            // [m_alloc] ||q||^2
+	DevPtr<float> d_qnrm;            // [m_alloc] ||q||^2 (fp16 form, inner product: of the filter-side query c_q q)
+	DevPtr<float> d_qscale;          // [m_alloc] c_q: the power of two the fp16 filter sees a query multiplied by (inner product; L2: 1)
 	float f16_scale = 0.0f;          // power of two; 0 = not built
 	float f16_bnmax = 0.0f;          // max ||b||^2 (host copy lives in d_bnmax[2])
 	DevPtr<float> d_theta;           // [m_alloc] (int32 thetas for the 8-bit GEMM form)
@@ -146,6 +147,7 @@ struct expann_index {
 	long opt_sample_pass = 1;        // fp16 form: one sampled class-maxima pass instead of the level ladder
 	long opt_tail_chunks = 1;        // scan_gemm_f16x: the last round's row chunks three times finer (pick_tail_chunks)
 	long opt_persist = 1;            // scan_gemm_f16x: resident workgroups pull (query tile, row chunk) items per XCD
+	long opt_ip_rescale = 1;         // fp16 form, inner product: the filter sees each query times a power of two (f16_query_prep_kernel)
 	long opt_scan_kernel = 0;        // 0 auto, 1 direct (scan_filter), 2 GEMM form on fp32 / int8
 	                                 // MFMA, 3 GEMM form on bf16 MFMA with the 3-term split
 	// profiling
@@ -342,8 +344,8 @@ int ensure_workspace(expann_index* h, size_t m, uint32_t cap) {
 		HIP_TRY(h, hipStreamSynchronize(h->async_stream));
 	if (m > h->m_alloc) {  // the per-query arrays grow together
 		h->m_alloc = 0;
-		for (DevPtr<float>* b : {std::addressof(h->d_qnrm), std::addressof(h->d_theta), std::addressof(h->d_tau[0]),
-		                         std::addressof(h->d_tau[1])}) {
+		for (DevPtr<float>* b : {std::addressof(h->d_qnrm), std::addressof(h->d_qscale), std::addressof(h->d_theta),
+		                         std::addressof(h->d_tau[0]), std::addressof(h->d_tau[1])}) {
 			b->reset();
 			HIP_TRY(h, hipMalloc(&*b, sizeof(float) * m));
 		}
@@ -406,7 +408,7 @@ const GemmBf16Variant kGemmBf16[] = {{64, scan_gemm_bf16x3_kernel<64>, "scan_gem
 
 using GemmF16Fn = void (*)(GemmF16Params);
 using SqnormFn = void (*)(const float*, uint32_t, float*);
-using F16PrepFn = void (*)(const float*, uint32_t, float, _Float16*, float*, uint32_t*, float*, uint32_t*);
+using F16PrepFn = void (*)(const float*, uint32_t, float, _Float16*, float*, uint32_t*, float*, uint32_t*, const float*, float*);
 struct GemmF16Variant {
 	int d;
 	GemmF16Fn scan;
@@ -522,10 +524,10 @@ int ensure_f16(expann_index* h, const GemmF16Variant* gf, hipStream_t st) {
 	const int ipm = h->metric == EXPANN_METRIC_IP ? 1 : 0;
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, gemm_f16_filter_eps(h->dim), abs_coef,
-	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16, ipm);
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bnorm_f16, ipm, (const float*)nullptr);
 	hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((h->n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   0, st, (const float*)nrm.p, (uint32_t)h->n, -gemm_f16_filter_eps(h->dim), -abs_coef,
-	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16, ipm);
+	                   (const float*)nullptr, 0.5f * scale * scale, h->d_bns_f16, ipm, (const float*)nullptr);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(st));  // tmp/nrm are freed on return
 	h->f16_scale = scale;
@@ -1197,6 +1199,7 @@ int sampled_pass_f16(expann_index* h, const GemmF16Variant* gvf, size_t m, size_
 	tp.abs_coef = std::ldexp(1.0f, -24) / h->f16_scale * std::sqrt((float)h->dim);
 	tp.inv_mul = 2.0f / (h->f16_scale * h->f16_scale);
 	tp.ip = ip ? 1 : 0;
+	tp.qscale = ip ? h->d_qscale.as<const float>() : nullptr;
 	tp.tau = d_tau;
 	tp.tau_row = d_tau_row;
 	tp.theta = h->d_theta;
@@ -1534,7 +1537,9 @@ int SearchPass::prepare_queries(bool* restart) {
 		hipLaunchKernelGGL(gvf->prep, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)), dim3(kBlock),
 		                   0, st, (const float*)d_queries, (uint32_t)m, h->f16_scale, h->d_q_split.as<_Float16>(),
 		                   h->d_qnrm, h->d_overflow + 2, from_host ? h->d_q.as<float>() : (float*)nullptr,
-		                   one_wg ? h->d_overflow : (uint32_t*)nullptr);
+		                   one_wg ? h->d_overflow : (uint32_t*)nullptr,
+		                   (ip && h->opt_ip_rescale) ? (const float*)(h->d_bnmax + 2) : (const float*)nullptr,
+		                   h->d_qscale.as<float>());
 		HIP_TRY(h, hipGetLastError());
 		if (from_host) {
 			d_queries = h->d_q;
@@ -1639,7 +1644,8 @@ int SearchPass::run_level(size_t li) {
 			hipLaunchKernelGGL(f16_terms_kernel, dim3((uint32_t)((m + kBlock - 1) / kBlock)),
 			                   dim3(kBlock), 0, st, h->d_qnrm.as<const float>(), (uint32_t)m,
 			                   gemm_f16_filter_eps(h->dim), f16_abs, (const float*)sp.tau,
-			                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0);
+			                   0.5f * h->f16_scale * h->f16_scale, h->d_theta, ip ? 1 : 0,
+			                   ip ? h->d_qscale.as<const float>() : (const float*)nullptr);
 		else
 			hipLaunchKernelGGL(gv->theta, dim3((uint32_t)((m + kRowsPerGroup - 1) / kRowsPerGroup)),
 			                   dim3(kBlock), 0, st, (const float*)d_queries, (uint32_t)m,
@@ -2548,6 +2554,8 @@ int expann_set_option(expann_index* h, const char* name, long value) {
 		h->opt_tail_chunks = value;
 	else if (!std::strcmp(name, "persist"))
 		h->opt_persist = value;
+	else if (!std::strcmp(name, "ip_rescale"))
+		h->opt_ip_rescale = value;
 	else if (!std::strcmp(name, "sample_pass"))
 		h->opt_sample_pass = value;
 	else if (!std::strcmp(name, "u8_exact"))

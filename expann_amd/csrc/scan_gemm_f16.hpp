@@ -117,11 +117,19 @@ __global__ __launch_bounds__(kBlock) void sqnorm_kernel(const float* x, uint32_t
 // Latency mode (m <= 16: a single workgroup): q may be pinned host memory -- the kernel then also
 // leaves a device copy in q_copy for the kernels that follow -- and zero_flags (the 8-word flag /
 // statistics block that maxabs_bits points into) is cleared here instead of by a memset launch.
+// Inner product (ip_ref != nullptr, round 3): the filter's slack eps (|q|^2 + |b|^2) bounds 2 eps |q| |b| tightly
+// only when the two norms are alike.  Ranks under the inner product do not change when a query is multiplied by
+// a positive constant, so the FILTER sees each query times a power of two c_q (exact) that brings |c_q q|^2 to
+// *ip_ref (the largest row norm: the rows that reach a top-k under the inner product are the large ones):
+// q16, qnrm and the range check are those of c_q q, qscale[i] = c_q; thresholds that arrive in true units are
+// multiplied by it (f16_terms_kernel), the sampled pass's own are in the scaled domain already, and the exact
+// re-rank reads the caller's queries.  (L2: c_q = 1.)
 template <int D>
 __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, uint32_t m, float scale,
                                                                 _Float16* q16, float* qnrm,
                                                                 uint32_t* maxabs_bits, float* q_copy,
-                                                                uint32_t* zero_flags) {
+                                                                uint32_t* zero_flags, const float* ip_ref,
+                                                                float* qscale) {
 	__shared__ uint32_t red[kBlock / 64];
 	if (zero_flags) {
 		if (threadIdx.x < 8)
@@ -135,21 +143,40 @@ __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, 
 	const float* src = q + (size_t)ii * D + l;
 	float acc = 0.0f;
 	uint32_t b = 0;
+	float vals[D / 16];
 #pragma unroll
 	for (int t = 0; t < D / 16; ++t) {
 		const float v = src[16 * t];
+		vals[t] = v;
 		acc = __builtin_fmaf(v, v, acc);
 		const uint32_t vb = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
 		b = vb > b ? vb : b;
-		if (i < m) {
-			q16[(size_t)i * D + l + 16 * t] = (_Float16)(v * scale);
-			if (q_copy)
-				q_copy[(size_t)i * D + l + 16 * t] = v;
-		}
 	}
 	acc = reduce16_ref_order(acc);
-	if (i < m && l == 0)
-		qnrm[i] = acc;
+	acc = __shfl(acc, lane & ~15);  // (the reference order is the first lane's: one value for the 16 lanes)
+	float c = 1.0f;
+	if (ip_ref) {
+		const float ref = ip_ref[0];
+		if (acc > 0.0f && ref > 0.0f && acc < 3.0e38f && ref < 3.0e38f) {
+			int e = (int)__builtin_rintf(0.5f * (__builtin_log2f(ref) - __builtin_log2f(acc)));
+			e = e < -40 ? -40 : (e > 40 ? 40 : e);
+			c = __builtin_ldexpf(1.0f, e);
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < D / 16; ++t) {
+		if (i < m) {
+			q16[(size_t)i * D + l + 16 * t] = (_Float16)(vals[t] * c * scale);
+			if (q_copy)
+				q_copy[(size_t)i * D + l + 16 * t] = vals[t];
+		}
+	}
+	if (i < m && l == 0) {
+		qnrm[i] = acc * c * c;
+		if (qscale)
+			qscale[i] = c;
+	}
+	b = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, b) * c);  // (max |c_q q|: what the fp16 range check is about)
 	for (int off = 32; off > 0; off >>= 1) {
 		const uint32_t o = (uint32_t)__shfl_xor((int)b, off);
 		b = o > b ? o : b;
@@ -174,16 +201,18 @@ __global__ __launch_bounds__(kBlock) void f16_query_prep_kernel(const float* q, 
 // E = eps (||q||^2 + ||b||^2) + abs (|q| + |b|), so with e(v) = eps v + abs sqrt(v):
 //   rows:    out = -e(nrm) * mul          queries: out = (2 tau + e(nrm)) * mul
 // and the kernel's test acc = theta' + q16.b16 >= bn' keeps every row with -q.b <= tau.
+// (qscale: the queries' filter-side factors c_q of f16_query_prep_kernel -- inner product only, nullptr = 1 -- :
+// nrm is already that of c_q q, a threshold in true units becomes c_q tau)
 __global__ __launch_bounds__(kBlock) void f16_terms_kernel(const float* nrm, uint32_t n, float eps,
                                                            float abs_coef, const float* tau,
-                                                           float mul, float* out, int ip) {
+                                                           float mul, float* out, int ip, const float* qscale) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n)
 		return;
 	const float v = nrm[i];
 	if (ip) {
 		const float e = v * eps + abs_coef * __builtin_sqrtf(v);
-		out[i] = (tau ? 2.0f * tau[i] + e : -e) * mul;
+		out[i] = (tau ? 2.0f * tau[i] * (qscale ? qscale[i] : 1.0f) + e : -e) * mul;
 		return;
 	}
 	const float t = v * (1.0f - eps) - abs_coef * __builtin_sqrtf(v);
@@ -399,6 +428,7 @@ struct SampleTauParams {
 	float* theta;        // [m] <- (tau - (||q||^2 (1-eps) - abs |q|)) * mul, as f16_terms_kernel
 	float mul;
 	uint32_t* cand_cnt;  // [m] <- 0 (the full scan's list counters)
+	const float* qscale; // inner product: the queries' filter-side factors c_q (tau is stored in true units: / c_q); or nullptr
 };
 // one thread: ord = ordered bits of the k-th largest g (0: fewer than k values) -> tau, theta', counter
 __device__ inline void sample_tau_finish(const SampleTauParams& p, uint32_t qi, uint32_t ord) {
@@ -413,7 +443,7 @@ __device__ inline void sample_tau_finish(const SampleTauParams& p, uint32_t qi, 
 		if (!(tau == tau))
 			tau = __builtin_inff();
 	}
-	p.tau[qi] = tau;
+	p.tau[qi] = (p.ip && p.qscale) ? tau / p.qscale[qi] : tau;  // (true units; theta' below stays in the filter's domain)
 	p.tau_row[qi] = 0xFFFFFFFFu;
 	p.theta[qi] = p.ip ? (2.0f * tau + qn * p.eps + p.abs_coef * __builtin_sqrtf(qn)) * p.mul
 	                   : (tau - (qn * (1.0f - p.eps) - p.abs_coef * __builtin_sqrtf(qn))) * p.mul;
