@@ -351,7 +351,10 @@ int expann_sharded_get_profile(expann_sharded* h, int shard, expann_profile* out
  * "async_search" (1: expann_search_device returns without the final host wait, see expann_sync),
  * "xcd_tolerance" (percent of modelled launch cost given up for an XCD-aligned row-chunk count,
  * default 3), "scan_chunks" (experiments: force the row-chunk count of the fp16 scan; 0 = model),
- * "sample_run", "debug" (bench / ablation switches). */
+ * "sample_run", "debug" (bench / ablation switches),
+ * "persist" (1 (default): the d = 128 fp16 scan runs as resident workgroups pulling work per XCD; 0: plain launch),
+ * "ip_rescale" (1 (default): inner product, fp16 form: the filter sees each query times a power of two that brings
+ * its norm to the largest row's -- ranks unchanged, results exact; 0: rounds 1-2's unscaled filter). */
 int expann_set_option(expann_index* h, const char* name, long value);
 
 #ifdef __cplusplus
