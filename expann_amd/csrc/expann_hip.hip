@@ -808,7 +808,12 @@ uint32_t sample_frac_for(const expann_index* h, size_t k) {
 		return (uint32_t)h->opt_sample_frac;
 	const double expo = h->dtype == EXPANN_DTYPE_F32 ? 0.3 : 0.5;
 	const double bytes = (double)h->n * (double)h->dim * (h->dtype == EXPANN_DTYPE_F32 ? 2.0 : 1.0);
-	const double size = (bytes >= 8 * 2.56e8 && k <= 32) ? std::min(3.0, std::pow(bytes / 2.56e8, 0.3)) : 1.0;
+	double size = (bytes >= 8 * 2.56e8 && k <= 32) ? std::min(3.0, std::pow(bytes / 2.56e8, 0.3)) : 1.0;
+	// (round 3, after the hits got cheaper -- lighter flush, keys made by the gather, pruned selects --
+	// profiles/sweep_frac_r3.sh: k = 100 on 1.25 M rows: 6 beats 8 by 2.3 % (3.28 vs 3.36 ms), on 10 M rows 8 - 12 are
+	// even: ~bytes^0.25 from C3's per-GPU shard on)
+	if (h->dtype == EXPANN_DTYPE_F32 && k > 32)
+		size = 0.75 * std::pow(std::max(1.0, bytes / 3.2e8), 0.25);
 	const double f = 16.0 * std::pow(10.0 / (double)std::max<size_t>(1, k), expo) * size;
 	return (uint32_t)std::min(48.0, std::max(4.0, std::round(f)));
 }
